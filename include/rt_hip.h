@@ -1,0 +1,189 @@
+/*
+ * rt_hip.h -- C ABI of librt_hip.so, the MI355X (gfx950) render backend.
+ *
+ * The library replaces one call of the reference:
+ *
+ *     raytracer_lib::render(&Scene, sqrt_rays_per_pixel, AntialiasMethod, cb) -> Framebuffer
+ *         (raytracer-lib/src/render.rs:7-23, called from raytracer-cli/src/main.rs:100)
+ *
+ * and mirrors the one call that must run before it so that a `Scene` exists at
+ * all without a Rust toolchain:
+ *
+ *     raytracer_lib::parse_scene(json, data_path, w, h, aspect, depth, shadows, normals)
+ *         (raytracer-lib/src/scene/mod.rs:378-715)
+ *
+ * Every function returns RT_OK (0) or a negative RT_ERR_* code and never
+ * throws or aborts; rt_last_error() returns the message of the calling
+ * thread's last failure.  All pointers are plain host pointers unless a
+ * parameter is documented as a device pointer.  No function retains a caller
+ * pointer after it returns.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#include "rt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)     /* bad argument, or a scene the reference rejects with Err */
+#define RT_ERR_PARSE (-2)       /* malformed JSON / OBJ (scene/mod.rs:388) */
+#define RT_ERR_UNSUPPORTED (-3) /* the reference panics here (unimplemented!()), or the feature
+                                   has no deterministic definition (thread_rng) */
+#define RT_ERR_DEVICE (-4)      /* HIP runtime failure */
+#define RT_ERR_IO (-5)          /* file could not be read */
+
+/* ------------------------------------------------------------------ */
+/* Scene construction on the host (mirror of parse_scene)              */
+/* ------------------------------------------------------------------ */
+
+/* The Option<> arguments of parse_scene (scene/mod.rs:378-387); a zero /
+ * negative value stands for None. */
+typedef struct RtParseArgs {
+    uint32_t image_width;    /* 0 -> DEFAULT_IMAGE_WIDTH 360  (prelude.rs:54) */
+    uint32_t image_height;   /* 0 -> DEFAULT_IMAGE_HEIGHT 360 (prelude.rs:55) */
+    double aspect_ratio;     /* <= 0 -> width / height        (scene/mod.rs:400) */
+    int32_t recursion_depth; /* < 0 -> DEFAULT_RECURSION_DEPTH 3 (prelude.rs:57) */
+    uint8_t disable_shadows;
+    uint8_t render_normals;
+    uint8_t _pad[2];
+} RtParseArgs;
+
+/* parse_scene(scene_json, scene_data_path, ...) -- scene/mod.rs:378.
+ * `scene_data_path` is the directory mesh `file` entries are relative to. */
+int rt_parse_scene(const char *scene_json, const char *scene_data_path,
+                   const RtParseArgs *args, RtScene **scene_out);
+
+/* The CLI's read_to_string + parent() + parse_scene sequence -- main.rs:51-67. */
+int rt_parse_scene_file(const char *scene_path, const RtParseArgs *args, RtScene **scene_out);
+
+/* Frees a scene returned by rt_parse_scene / rt_parse_scene_file. */
+void rt_scene_destroy(RtScene *scene);
+
+/* ------------------------------------------------------------------ */
+/* Backend and device-resident scene                                    */
+/* ------------------------------------------------------------------ */
+
+typedef struct RtBackend RtBackend;
+typedef struct RtDeviceScene RtDeviceScene;
+
+/* One backend per GPU.  `device_ordinal` is the HIP device index. */
+int rt_backend_create(int device_ordinal, RtBackend **backend_out);
+void rt_backend_destroy(RtBackend *backend);
+
+/* Flattens the scene into HBM: builds the top-level and per-mesh BVHs with the
+ * reference's split rule (geometry/bvh.rs:36-87), linearises them, and uploads
+ * fp32 traversal records plus the f64 originals.  Replaces the tree build that
+ * parse_scene performs at scene/mod.rs:699-700 and geometry/mesh.rs:59. */
+int rt_scene_upload(RtBackend *backend, const RtScene *scene, RtDeviceScene **dev_scene_out);
+void rt_scene_free(RtDeviceScene *dev_scene);
+
+/* ------------------------------------------------------------------ */
+/* render                                                               */
+/* ------------------------------------------------------------------ */
+
+/* antialias.rs:6-10.  Only NORMAL is deterministic; the other two draw from
+ * an OS-seeded RNG in the reference and are rejected with RT_ERR_UNSUPPORTED. */
+enum { RT_AA_NORMAL = 0, RT_AA_JITTERED = 1, RT_AA_RANDOM = 2 };
+
+/* Traversal policy.  Both produce the same closest hits except at exact ties.
+ *  FAST:            children visited near-first; shadow rays stop at the first
+ *                   blocker (only "occluded or not" is defined for them).
+ *  REFERENCE_ORDER: children visited left-then-right as geometry/bvh.rs:112-122
+ *                   does, shadow rays run to the closest blocker as
+ *                   light/point.rs:35 does, so blocker ids are comparable. */
+enum { RT_MODE_FAST = 0, RT_MODE_REFERENCE_ORDER = 1 };
+
+typedef struct RtRenderArgs {
+    uint16_t sqrt_rays_per_pixel; /* render.rs:9 */
+    uint16_t _pad0;
+    int32_t antialias_method;     /* render.rs:10 */
+    int32_t mode;                 /* RT_MODE_* */
+    /* Image partition for multi-GPU rendering.  The image is cut into
+     * tile_w x tile_h tiles, numbered row-major; tile k of tile-row r belongs
+     * to part (k + r) % part_count.  part_count <= 1 renders everything. */
+    uint32_t tile_w, tile_h;      /* 0 -> 32 */
+    uint32_t part_index, part_count;
+} RtRenderArgs;
+
+/* Optional per-sample outputs.  Sample s of pixel (i, j) is
+ *   s = (i + j * width) * n*n + p * n + q     (render.rs:64-65 loop order).
+ * Any pointer may be NULL.  Shape ids index RtScene.shapes; tri ids index the
+ * mesh's triangles in file order (-1 when the hit is not inside a mesh).
+ * -1 in a shape id means "no hit". */
+typedef struct RtRayIds {
+    int32_t *primary_shape; /* first hit of the camera ray */
+    int32_t *primary_tri;
+    int32_t *final_shape;   /* hit that was finally shaded after mirror bounces */
+    int32_t *final_tri;
+    int32_t *bounces;       /* mirror bounces traced for this sample */
+    /* n_point_lights entries per sample, in RtScene.lights order restricted to
+     * point lights: blocking shape id, -1 = light visible, -2 = no shadow ray. */
+    int32_t *shadow_shape;
+    int32_t *shadow_tri;
+} RtRayIds;
+
+enum {
+    RT_K_RAYGEN = 0,
+    RT_K_TRACE_CLOSEST = 1,
+    RT_K_SHADE = 2,
+    RT_K_TRACE_SHADOW = 3,
+    RT_K_ACCUMULATE = 4,
+    RT_K_RESOLVE = 5,
+    RT_K_COUNT = 8
+};
+
+typedef struct RtStats {
+    uint64_t primary_rays;   /* width * height * n*n of the rendered part */
+    uint64_t secondary_rays; /* mirror bounces traced (shader/perfect_mirror.rs:27) */
+    uint64_t shadow_rays;    /* shaded hits x point lights (light/point.rs:35) */
+    uint64_t shaded_hits;
+    double render_ms;               /* device time, first kernel start to last kernel end */
+    double kernel_ms[RT_K_COUNT];   /* summed per kernel class, HIP events on the render stream */
+    uint32_t kernel_launches[RT_K_COUNT];
+} RtStats;
+
+/* render(&scene, sqrt_rpp, aa, cb) -> Framebuffer  -- render.rs:7-23.
+ * `fb_rgb` is caller-owned host memory, width*height*3 floats, laid out as
+ * Framebuffer::pixels (framebuffer.rs:21-31): index (i + j*width)*3, row j = 0
+ * is the bottom of the image.  With part_count > 1 only the owned tiles'
+ * pixels are written.  Blocking. */
+int rt_render(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
+              float *fb_rgb, const RtRayIds *ids_host, RtStats *stats_out);
+
+/* Same, but `fb_rgb_dev` and the `ids_dev` arrays are DEVICE pointers and the
+ * work is enqueued on `hip_stream` (a hipStream_t, NULL = the backend's own
+ * stream).  Returns after enqueueing when stats_out is NULL; with stats_out it
+ * waits for the stream and fills the counters and timings. */
+int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
+                     float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream,
+                     RtStats *stats_out);
+
+/* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
+ * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).
+ * origins/directions: n x 3 doubles (host).  Outputs (host): t (f32, unchanged
+ * tmax when nothing is hit), shape id, tri id. */
+int rt_trace_rays(RtBackend *backend, const RtDeviceScene *dev_scene, uint64_t n,
+                  const double *origins, const double *directions, const double *tmin,
+                  const double *tmax, int32_t mode, float *t_out, int32_t *shape_out,
+                  int32_t *tri_out);
+
+/* save_to_png's pixel conversion -- raytracer-cli/src/output/png_export.rs:4-10:
+ * out(x, y) = round(clamp(fb(x, height-1-y), 0, 1) * 255) in f32, rows top-down.
+ * `rgb8_out` holds width*height*3 bytes. */
+int rt_framebuffer_to_rgb8(const float *fb_rgb, uint32_t width, uint32_t height, uint8_t *rgb8_out);
+
+/* Number of point lights of an uploaded scene (the stride of RtRayIds.shadow_*). */
+uint32_t rt_scene_point_light_count(const RtDeviceScene *dev_scene);
+
+/* Message of the calling thread's most recent failure ("" if none). */
+const char *rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

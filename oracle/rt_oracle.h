@@ -1,0 +1,63 @@
+/* rt_oracle.h -- C interface of the CPU oracle (test infrastructure only; see
+ * rt_oracle.cpp).  Loaded by the test harness through ctypes. */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/rt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-sample outputs, same indexing and meaning as RtRayIds in rt_hip.h:
+ * s = (i + j*width)*n*n + p*n + q.  Any pointer may be NULL. */
+typedef struct OracleOutputs {
+    int32_t *primary_shape;
+    int32_t *primary_tri;
+    int32_t *final_shape;
+    int32_t *final_tri;
+    int32_t *bounces;
+    int32_t *shadow_shape; /* n_point_lights per sample: blocker, -1 visible, -2 no ray */
+    int32_t *shadow_tri;
+} OracleOutputs;
+
+/* Index 0 = camera rays, 1 = mirror rays, 2 = shadow rays. */
+typedef struct OracleCounters {
+    uint64_t rays[3];
+    uint64_t node_tests[3];     /* BVH nodes entered (one box test each), bvh.rs:95 */
+    uint64_t sphere_tests[3];
+    uint64_t triangle_tests[3];
+    uint64_t box_tests[3];
+    uint64_t instance_visits[3];
+    uint64_t shaded_hits;
+} OracleCounters;
+
+/* geometry_bits: 64 = the reference CLI's arithmetic; 32 = the same formulas in f32.
+ * threads: OpenMP threads over pixel columns (<= 0: runtime default). */
+int oracle_render(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int geometry_bits, int threads,
+                  float *fb_rgb, const OracleOutputs *outputs, OracleCounters *counters);
+
+int oracle_trace_rays(const RtScene *scene, uint64_t n, const double *origins, const double *directions,
+                      const double *tmin, const double *tmax, int geometry_bits, double *t_out,
+                      int32_t *shape_out, int32_t *tri_out, double *normal_out);
+
+uint32_t oracle_point_light_count(const RtScene *scene);
+
+int oracle_bbox_hit(const double mn[3], const double mx[3], const double o[3], const double d[3],
+                    double tmin, double tmax, double *t_out);
+
+int oracle_primitive_hit(int kind, const double p0[3], const double p1[3], const double p2[3], double radius,
+                         const double o[3], const double d[3], double tmin, double tmax, double *t_out,
+                         double normal_out[3]);
+
+void oracle_camera_basis(const double view[3], double u_out[3], double v_out[3], double w_out[3]);
+
+int64_t oracle_bvh_dump(const RtScene *scene, int32_t which, int64_t cap_nodes, int64_t cap_prims,
+                        int32_t *kinds_out, int32_t *prims_out, double *boxes_out, int64_t *n_prims_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,478 @@
+"""Host-side mirror of the reference's public API over the C ABI of librt_hip.so.
+
+The reference crate exports (raytracer-lib/src/lib.rs:17-23)
+
+    parse_scene(json, data_path, width, height, aspect, depth, disable_shadows, render_normals) -> Scene
+    render(&Scene, sqrt_rays_per_pixel, AntialiasMethod, per_pixel_cb) -> Framebuffer
+
+This module keeps those two names, argument meanings and error behaviour
+(`parse_scene` raises where the reference returns Err or panics; `render` has no
+error path of its own besides device failures) and forwards everything to the
+library declared in include/rt_hip.h.  There is no CPU implementation here: if
+the HIP library cannot be loaded, or no GPU is present, calls raise.
+
+Python is only the harness language of this repository (tests, benchmark); the
+boundary a Rust caller would bind is the C header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt_hip.so")
+
+RT_OK = 0
+RT_ERR_INVALID = -1
+RT_ERR_PARSE = -2
+RT_ERR_UNSUPPORTED = -3
+RT_ERR_DEVICE = -4
+RT_ERR_IO = -5
+
+RT_MODE_FAST = 0
+RT_MODE_REFERENCE_ORDER = 1
+RT_K_COUNT = 8
+KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_shadow", "accumulate", "resolve")
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rt error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class AntialiasMethod(enum.IntEnum):
+    """antialias.rs:6-10"""
+
+    Normal = 0
+    Jittered = 1
+    Random = 2
+
+
+# ---- ctypes mirrors of include/rt_scene.h (only what the harness reads) -------------
+
+
+class RtVec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("pixels_x", C.c_uint32),
+        ("pixels_y", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("position", RtVec3),
+        ("u", RtVec3),
+        ("v", RtVec3),
+        ("w", RtVec3),
+        ("left", C.c_double),
+        ("right", C.c_double),
+        ("top", C.c_double),
+        ("bottom", C.c_double),
+        ("focal_length", C.c_double),
+    ]
+
+
+class RtShader(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("diffuse", C.c_float * 3),
+        ("specular", C.c_float * 3),
+        ("shininess", C.c_float),
+        ("roughness", C.c_double),
+        ("samples", C.c_uint32),
+        ("_pad", C.c_uint32),
+    ]
+
+
+class RtLight(C.Structure):
+    _fields_ = [("type", C.c_int32), ("intensity", C.c_float * 3), ("position", RtVec3)]
+
+
+class RtShape(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("shader", C.c_int32),
+        ("mesh", C.c_int32),
+        ("proto", C.c_int32),
+        ("p0", RtVec3),
+        ("p1", RtVec3),
+        ("p2", RtVec3),
+        ("radius", C.c_double),
+        ("inv_transform", C.c_double * 16),
+        ("normal_matrix", C.c_double * 16),
+        ("bbox_min", RtVec3),
+        ("bbox_max", RtVec3),
+    ]
+
+
+class RtMesh(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint64), ("vertices", C.POINTER(C.c_double))]
+
+
+class RtScene(C.Structure):
+    _fields_ = [
+        ("camera", RtCamera),
+        ("background", C.c_float * 3),
+        ("recursion_depth", C.c_uint16),
+        ("disable_shadows", C.c_uint8),
+        ("_pad0", C.c_uint8),
+        ("image_width", C.c_uint32),
+        ("image_height", C.c_uint32),
+        ("n_shapes", C.c_uint32),
+        ("n_protos", C.c_uint32),
+        ("n_meshes", C.c_uint32),
+        ("n_shaders", C.c_uint32),
+        ("n_lights", C.c_uint32),
+        ("_pad1", C.c_uint32),
+        ("shapes", C.POINTER(RtShape)),
+        ("protos", C.POINTER(RtShape)),
+        ("meshes", C.POINTER(RtMesh)),
+        ("shaders", C.POINTER(RtShader)),
+        ("lights", C.POINTER(RtLight)),
+    ]
+
+
+class RtParseArgs(C.Structure):
+    _fields_ = [
+        ("image_width", C.c_uint32),
+        ("image_height", C.c_uint32),
+        ("aspect_ratio", C.c_double),
+        ("recursion_depth", C.c_int32),
+        ("disable_shadows", C.c_uint8),
+        ("render_normals", C.c_uint8),
+        ("_pad", C.c_uint8 * 2),
+    ]
+
+
+class RtRenderArgs(C.Structure):
+    _fields_ = [
+        ("sqrt_rays_per_pixel", C.c_uint16),
+        ("_pad0", C.c_uint16),
+        ("antialias_method", C.c_int32),
+        ("mode", C.c_int32),
+        ("tile_w", C.c_uint32),
+        ("tile_h", C.c_uint32),
+        ("part_index", C.c_uint32),
+        ("part_count", C.c_uint32),
+    ]
+
+
+class RtRayIds(C.Structure):
+    _fields_ = [
+        ("primary_shape", C.c_void_p),
+        ("primary_tri", C.c_void_p),
+        ("final_shape", C.c_void_p),
+        ("final_tri", C.c_void_p),
+        ("bounces", C.c_void_p),
+        ("shadow_shape", C.c_void_p),
+        ("shadow_tri", C.c_void_p),
+    ]
+
+
+ID_FIELDS = ("primary_shape", "primary_tri", "final_shape", "final_tri", "bounces", "shadow_shape", "shadow_tri")
+
+
+class RtStats(C.Structure):
+    _fields_ = [
+        ("primary_rays", C.c_uint64),
+        ("secondary_rays", C.c_uint64),
+        ("shadow_rays", C.c_uint64),
+        ("shaded_hits", C.c_uint64),
+        ("render_ms", C.c_double),
+        ("kernel_ms", C.c_double * RT_K_COUNT),
+        ("kernel_launches", C.c_uint32 * RT_K_COUNT),
+    ]
+
+    def total_rays(self) -> int:
+        return int(self.primary_rays + self.secondary_rays + self.shadow_rays)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads librt_hip.so (built in-tree by `make -C rust-raytracer_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(RT_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}`")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_parse_scene.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RtParseArgs), C.POINTER(C.POINTER(RtScene))]
+    L.rt_parse_scene_file.argtypes = [C.c_char_p, C.POINTER(RtParseArgs), C.POINTER(C.POINTER(RtScene))]
+    L.rt_scene_destroy.argtypes = [C.POINTER(RtScene)]
+    L.rt_scene_destroy.restype = None
+    L.rt_backend_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rt_backend_destroy.argtypes = [vp]
+    L.rt_backend_destroy.restype = None
+    L.rt_scene_upload.argtypes = [vp, C.POINTER(RtScene), C.POINTER(vp)]
+    L.rt_scene_free.argtypes = [vp]
+    L.rt_scene_free.restype = None
+    L.rt_render.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), C.POINTER(RtStats)]
+    L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp, C.POINTER(RtStats)]
+    L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
+    L.rt_framebuffer_to_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.rt_scene_point_light_count.argtypes = [vp]
+    L.rt_scene_point_light_count.restype = C.c_uint32
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
+
+
+class Scene:
+    """Owner of an RtScene built by the loader (the reference's `Scene`, scene/mod.rs:14-25)."""
+
+    def __init__(self, ptr):
+        self._ptr = ptr
+
+    @property
+    def c(self) -> RtScene:
+        return self._ptr.contents
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+    @property
+    def image_width(self) -> int:
+        return int(self.c.image_width)
+
+    @property
+    def image_height(self) -> int:
+        return int(self.c.image_height)
+
+    @property
+    def n_point_lights(self) -> int:
+        return sum(1 for i in range(self.c.n_lights) if self.c.lights[i].type == 0)
+
+    def close(self) -> None:
+        if self._ptr is not None:
+            lib().rt_scene_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _parse_args(image_width, image_height, aspect_ratio, recursion_depth, disable_shadows, render_normals) -> RtParseArgs:
+    a = RtParseArgs()
+    a.image_width = int(image_width or 0)
+    a.image_height = int(image_height or 0)
+    a.aspect_ratio = float(aspect_ratio) if aspect_ratio else 0.0
+    a.recursion_depth = -1 if recursion_depth is None else int(recursion_depth)
+    a.disable_shadows = 1 if disable_shadows else 0
+    a.render_normals = 1 if render_normals else 0
+    return a
+
+
+def parse_scene(
+    scene_json: str,
+    scene_data_path: str,
+    image_width: Optional[int] = None,
+    image_height: Optional[int] = None,
+    aspect_ratio: Optional[float] = None,
+    recursion_depth: Optional[int] = None,
+    disable_shadows: bool = False,
+    render_normals: bool = False,
+) -> Scene:
+    """parse_scene -- scene/mod.rs:378-387 (same argument order and defaults)."""
+    a = _parse_args(image_width, image_height, aspect_ratio, recursion_depth, disable_shadows, render_normals)
+    out = C.POINTER(RtScene)()
+    _check(lib().rt_parse_scene(scene_json.encode(), scene_data_path.encode(), C.byref(a), C.byref(out)))
+    return Scene(out)
+
+
+def parse_scene_file(scene_path: str, **kw) -> Scene:
+    """The CLI's read + parse sequence -- raytracer-cli/src/main.rs:51-67."""
+    a = _parse_args(
+        kw.get("image_width"), kw.get("image_height"), kw.get("aspect_ratio"), kw.get("recursion_depth"),
+        kw.get("disable_shadows", False), kw.get("render_normals", False),
+    )
+    out = C.POINTER(RtScene)()
+    _check(lib().rt_parse_scene_file(scene_path.encode(), C.byref(a), C.byref(out)))
+    return Scene(out)
+
+
+class Framebuffer:
+    """framebuffer.rs:4-8: width, height, pixels[i + j*width] = [r, g, b], row 0 at the bottom."""
+
+    def __init__(self, width: int, height: int, pixels: Optional[np.ndarray] = None):
+        self.width = width
+        self.height = height
+        self.pixels = np.zeros((height, width, 3), np.float32) if pixels is None else pixels
+
+    def get_pixel(self, i: int, j: int) -> np.ndarray:
+        return self.pixels[j, i]
+
+    def to_rgb8(self) -> np.ndarray:
+        """save_to_png's conversion (raytracer-cli/src/output/png_export.rs:4-10): top-down rows of u8."""
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        src = np.ascontiguousarray(self.pixels, np.float32)
+        _check(lib().rt_framebuffer_to_rgb8(src.ctypes.data, self.width, self.height, out.ctypes.data))
+        return out
+
+
+class RayIds:
+    """Per-sample id arrays (RtRayIds), host numpy."""
+
+    def __init__(self, n_samples: int, n_point_lights: int):
+        self.primary_shape = np.full(n_samples, -1, np.int32)
+        self.primary_tri = np.full(n_samples, -1, np.int32)
+        self.final_shape = np.full(n_samples, -1, np.int32)
+        self.final_tri = np.full(n_samples, -1, np.int32)
+        self.bounces = np.zeros(n_samples, np.int32)
+        self.shadow_shape = np.full((n_samples, max(n_point_lights, 0)), -2, np.int32)
+        self.shadow_tri = np.full((n_samples, max(n_point_lights, 0)), -2, np.int32)
+
+    def as_struct(self) -> RtRayIds:
+        s = RtRayIds()
+        for f in ID_FIELDS:
+            arr = getattr(self, f)
+            setattr(s, f, arr.ctypes.data if arr.size else None)
+        return s
+
+
+class Backend:
+    """One GPU: rt_backend_create / rt_backend_destroy."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().rt_backend_create(device, C.byref(self._h)))
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def upload(self, scene: Scene) -> "DeviceScene":
+        h = C.c_void_p()
+        _check(lib().rt_scene_upload(self._h, scene.ptr, C.byref(h)))
+        return DeviceScene(self, scene, h)
+
+    def close(self) -> None:
+        if self._h:
+            lib().rt_backend_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceScene:
+    def __init__(self, backend: Backend, scene: Scene, handle):
+        self.backend = backend
+        self.scene = scene
+        self._h = handle
+        self.width = scene.image_width
+        self.height = scene.image_height
+        self.n_point_lights = int(lib().rt_scene_point_light_count(handle))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self) -> None:
+        if self._h:
+            lib().rt_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
+                    tile=(0, 0), part=(0, 1)) -> RtRenderArgs:
+        a = RtRenderArgs()
+        a.sqrt_rays_per_pixel = int(sqrt_rays_per_pixel)
+        a.antialias_method = int(antialias_method)
+        a.mode = int(mode)
+        a.tile_w, a.tile_h = int(tile[0]), int(tile[1])
+        a.part_index, a.part_count = int(part[0]), int(part[1])
+        return a
+
+    def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
+               want_ids: bool = False, tile=(0, 0), part=(0, 1)):
+        """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats)."""
+        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part)
+        fb = Framebuffer(self.width, self.height)
+        ids = RayIds(self.width * self.height * int(sqrt_rays_per_pixel) ** 2, self.n_point_lights) if want_ids else None
+        ids_struct = ids.as_struct() if ids is not None else None
+        stats = RtStats()
+        _check(
+            lib().rt_render(
+                self.backend.handle, self._h, C.byref(a), fb.pixels.ctypes.data,
+                C.byref(ids_struct) if ids_struct is not None else None, C.byref(stats),
+            )
+        )
+        return fb, ids, stats
+
+    def trace_rays(self, origins, directions, tmin, tmax, mode=RT_MODE_FAST):
+        """BVH::closest_hit (geometry/bvh.rs:140) on caller-supplied rays."""
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float64), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float64), (n,)))
+        t = np.empty(n, np.float32)
+        shape = np.empty(n, np.int32)
+        tri = np.empty(n, np.int32)
+        _check(
+            lib().rt_trace_rays(
+                self.backend.handle, self._h, n, o.ctypes.data, d.ctypes.data, tmin.ctypes.data, tmax.ctypes.data,
+                int(mode), t.ctypes.data, shape.ctypes.data, tri.ctypes.data,
+            )
+        )
+        return t, shape, tri
+
+
+def render(scene: Scene, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, per_pixel_cb=None,
+           device: int = 0, mode: int = RT_MODE_FAST) -> Framebuffer:
+    """Drop-in for raytracer_lib::render (render.rs:7-12).
+
+    `per_pixel_cb` is accepted for signature parity and called once, after the
+    frame is complete, with no arguments: a GPU backend has no per-pixel moment
+    on the calling thread (the reference calls it once per pixel, render.rs:80-82,
+    only to advance a progress bar).
+    """
+    be = Backend(device)
+    try:
+        ds = be.upload(scene)
+        try:
+            fb, _, _ = ds.render(sqrt_rays_per_pixel, antialias_method, mode)
+        finally:
+            ds.close()
+    finally:
+        be.close()
+    if per_pixel_cb is not None:
+        per_pixel_cb()
+    return fb
+
+
+def save_png(path: str, fb: Framebuffer) -> None:
+    """output::save -- raytracer-cli/src/output/mod.rs:7-17 (only .png is supported there too)."""
+    if not path.lower().endswith(".png"):
+        raise RtError(RT_ERR_UNSUPPORTED, "Unsupported file format")
+    from PIL import Image
+
+    Image.fromarray(fb.to_rgb8(), "RGB").save(path)

@@ -1,0 +1,294 @@
+// bvh_build.cpp -- see bvh_build.h.  Host code, f64, runs once per scene.
+
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rt {
+
+namespace {
+
+constexpr size_t kMaxShapes = 4;  // BVHNode::MAX_SHAPES, geometry/bvh.rs:34
+
+void combine(const double amin[3], const double amax[3], const double bmin[3], const double bmax[3],
+             double omin[3], double omax[3]) {  // BBox::combine, geometry/bbox.rs:23-36
+    for (int k = 0; k < 3; ++k) {
+        omin[k] = std::fmin(amin[k], bmin[k]);
+        omax[k] = std::fmax(amax[k], bmax[k]);
+    }
+}
+
+struct Builder {
+    std::vector<BuildItem> &items;
+    Tree &tree;
+
+    // Builds the subtree over items[lo, hi) and returns its node index.
+    int32_t build(size_t lo, size_t hi, int axis, int inner_above) {
+        const int32_t me = (int32_t)tree.nodes.size();
+        tree.nodes.emplace_back();
+        if (hi - lo <= kMaxShapes) {
+            // leaf: shapes stay in incoming order; box = left fold of combine (bvh.rs:38-57)
+            double bmin[3], bmax[3];
+            std::memcpy(bmin, items[lo].bmin, sizeof(bmin));
+            std::memcpy(bmax, items[lo].bmax, sizeof(bmax));
+            for (size_t i = lo + 1; i < hi; ++i) combine(bmin, bmax, items[i].bmin, items[i].bmax, bmin, bmax);
+            TreeNode &n = tree.nodes[(size_t)me];
+            std::memcpy(n.bmin, bmin, sizeof(bmin));
+            std::memcpy(n.bmax, bmax, sizeof(bmax));
+            n.first = (uint32_t)tree.order.size();
+            n.count = (uint32_t)(hi - lo);
+            for (size_t i = lo; i < hi; ++i) tree.order.push_back(items[i].id);
+            tree.inner_depth = std::max(tree.inner_depth, inner_above);
+            return me;
+        }
+        // stable sort on the centroid coordinate of the current axis (bvh.rs:60-68)
+        std::stable_sort(items.begin() + (long)lo, items.begin() + (long)hi,
+                         [axis](const BuildItem &p, const BuildItem &q) { return p.centroid[axis] < q.centroid[axis]; });
+        const size_t mid = lo + (hi - lo) / 2;  // bvh.rs:71-72
+        const int next = (axis + 1) % 3;        // bvh.rs:15-21
+        const int32_t l = build(lo, mid, next, inner_above + 1);
+        const int32_t r = build(mid, hi, next, inner_above + 1);
+        TreeNode &n = tree.nodes[(size_t)me];
+        n.left = l;
+        n.right = r;
+        combine(tree.nodes[(size_t)l].bmin, tree.nodes[(size_t)l].bmax, tree.nodes[(size_t)r].bmin,
+                tree.nodes[(size_t)r].bmax, n.bmin, n.bmax);
+        return me;
+    }
+};
+
+// f64 box -> f32 box.  A strictly positive extent is rounded outward so the
+// fp32 box never excludes a point the f64 box contains; a zero extent stays
+// zero, because the reference never hits a flat box (bbox.rs:89,104,119) and a
+// padded one would become visible.
+void box_to_f32(const double bmin[3], const double bmax[3], float omin[3], float omax[3]) {
+    for (int k = 0; k < 3; ++k) {
+        float lo = (float)bmin[k], hi = (float)bmax[k];
+        if (bmin[k] < bmax[k]) {
+            if ((double)lo > bmin[k]) lo = std::nextafterf(lo, -INFINITY);
+            if ((double)hi < bmax[k]) hi = std::nextafterf(hi, INFINITY);
+        }
+        omin[k] = lo;
+        omax[k] = hi;
+    }
+}
+
+// Emits the subtree `t` of `tree` into out.nodes and returns the reference a
+// parent stores for it.  `prim_base` is added to leaf offsets.
+int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes) {
+    const TreeNode &n = tree.nodes[(size_t)t];
+    if (n.count > 0) return rt_make_leaf_ref(prim_base + n.first, n.count);
+    const int32_t me = (int32_t)nodes.size();
+    nodes.emplace_back();
+    const TreeNode &l = tree.nodes[(size_t)n.left];
+    const TreeNode &r = tree.nodes[(size_t)n.right];
+    RtNode rec{};
+    box_to_f32(l.bmin, l.bmax, rec.lmin, rec.lmax);
+    box_to_f32(r.bmin, r.bmax, rec.rmin, rec.rmax);
+    nodes[(size_t)me] = rec;
+    const int32_t lref = emit(tree, n.left, prim_base, nodes);
+    const int32_t rref = emit(tree, n.right, prim_base, nodes);
+    nodes[(size_t)me].left = lref;
+    nodes[(size_t)me].right = rref;
+    return me;
+}
+
+// Header node: its left child is the tree's root (with the root's own box, which
+// the reference tests on entry, bvh.rs:95), its right child is absent.
+int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNode> &nodes) {
+    const int32_t header = (int32_t)nodes.size();
+    nodes.emplace_back();
+    RtNode rec{};
+    box_to_f32(tree.nodes[0].bmin, tree.nodes[0].bmax, rec.lmin, rec.lmax);
+    for (int k = 0; k < 3; ++k) {
+        rec.rmin[k] = INFINITY;
+        rec.rmax[k] = -INFINITY;
+    }
+    rec.right = RT_REF_NONE;
+    nodes[(size_t)header] = rec;
+    const int32_t root_ref = emit(tree, 0, prim_base, nodes);
+    nodes[(size_t)header].left = root_ref;
+    return header;
+}
+
+void set3(double dst[3], const RtVec3 &v) {
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+}
+
+// Bounding box and centroid of a shape as the reference's constructors compute them.
+bool shape_bounds(const RtScene &scene, const RtShape &s, const std::vector<Tree> &blas, BuildItem &it) {
+    switch (s.type) {
+    case RT_SHAPE_SPHERE:  // sphere.rs:23-26, 50-52
+        it.bmin[0] = s.p0.x - s.radius; it.bmin[1] = s.p0.y - s.radius; it.bmin[2] = s.p0.z - s.radius;
+        it.bmax[0] = s.p0.x + s.radius; it.bmax[1] = s.p0.y + s.radius; it.bmax[2] = s.p0.z + s.radius;
+        set3(it.centroid, s.p0);
+        return true;
+    case RT_SHAPE_BOX:  // cuboid.rs:18, 55-57; bbox.rs:18
+        set3(it.bmin, s.p0);
+        set3(it.bmax, s.p1);
+        for (int k = 0; k < 3; ++k) it.centroid[k] = (it.bmin[k] + it.bmax[k]) * 0.5;
+        return true;
+    case RT_SHAPE_TRIANGLE: {  // triangle.rs:23-32, 58-60
+        const double a[3] = {s.p0.x, s.p0.y, s.p0.z}, b[3] = {s.p1.x, s.p1.y, s.p1.z}, c[3] = {s.p2.x, s.p2.y, s.p2.z};
+        for (int k = 0; k < 3; ++k) {
+            it.bmin[k] = std::fmin(std::fmin(a[k], b[k]), c[k]);
+            it.bmax[k] = std::fmax(std::fmax(a[k], b[k]), c[k]);
+            it.centroid[k] = (a[k] + b[k] + c[k]) / 3.0;
+        }
+        return true;
+    }
+    case RT_SHAPE_MESH: {  // mesh.rs:59-60, 83-85
+        if (s.mesh < 0 || (uint32_t)s.mesh >= scene.n_meshes) return false;
+        const TreeNode &root = blas[(size_t)s.mesh].nodes[0];
+        std::memcpy(it.bmin, root.bmin, sizeof(it.bmin));
+        std::memcpy(it.bmax, root.bmax, sizeof(it.bmax));
+        for (int k = 0; k < 3; ++k) it.centroid[k] = (it.bmin[k] + it.bmax[k]) * 0.5;
+        return true;
+    }
+    case RT_SHAPE_INSTANCE:  // instance.rs:42, 67-69
+        set3(it.bmin, s.bbox_min);
+        set3(it.bmax, s.bbox_max);
+        for (int k = 0; k < 3; ++k) it.centroid[k] = (it.bmin[k] + it.bmax[k]) * 0.5;
+        return true;
+    default: return false;
+    }
+}
+
+// fp32 payload of a sphere / box / triangle.
+void fill_payload(const RtShape &s, float f[12]) {
+    std::memset(f, 0, 12 * sizeof(float));
+    switch (s.type) {
+    case RT_SHAPE_SPHERE:
+        f[0] = (float)s.p0.x; f[1] = (float)s.p0.y; f[2] = (float)s.p0.z; f[3] = (float)s.radius;
+        break;
+    case RT_SHAPE_BOX:
+        f[0] = (float)s.p0.x; f[1] = (float)s.p0.y; f[2] = (float)s.p0.z;
+        f[3] = (float)s.p1.x; f[4] = (float)s.p1.y; f[5] = (float)s.p1.z;
+        break;
+    case RT_SHAPE_TRIANGLE:
+        f[0] = (float)s.p0.x; f[1] = (float)s.p0.y; f[2] = (float)s.p0.z;
+        f[3] = (float)(s.p0.x - s.p1.x); f[4] = (float)(s.p0.y - s.p1.y); f[5] = (float)(s.p0.z - s.p1.z);
+        f[6] = (float)(s.p0.x - s.p2.x); f[7] = (float)(s.p0.y - s.p2.y); f[8] = (float)(s.p0.z - s.p2.z);
+        break;
+    default: break;
+    }
+}
+
+}  // namespace
+
+Tree build_tree(std::vector<BuildItem> items) {
+    Tree tree;
+    if (items.empty()) return tree;
+    tree.nodes.reserve(items.size());
+    tree.order.reserve(items.size());
+    Builder b{items, tree};
+    b.build(0, items.size(), 0, 0);
+    return tree;
+}
+
+std::string flatten_scene(const RtScene &scene, FlatScene &out) {
+    out = FlatScene();
+    if (scene.n_shapes == 0) return "scene has no shapes";
+
+    // ---- one tree per mesh (geometry/mesh.rs:39-59)
+    uint64_t tri_total = 0;
+    for (uint32_t m = 0; m < scene.n_meshes; ++m) {
+        const RtMesh &mesh = scene.meshes[m];
+        if (mesh.n_triangles == 0 || !mesh.vertices) return "mesh without triangles";
+        out.mesh_tri_base.push_back(tri_total);
+        tri_total += mesh.n_triangles;
+        if (tri_total >= (1ull << 28)) return "too many mesh triangles for the 28-bit leaf offset";
+        std::vector<BuildItem> items((size_t)mesh.n_triangles);
+        for (uint64_t i = 0; i < mesh.n_triangles; ++i) {
+            const double *v = mesh.vertices + i * 9;
+            BuildItem &it = items[(size_t)i];
+            for (int k = 0; k < 3; ++k) {
+                it.bmin[k] = std::fmin(std::fmin(v[k], v[3 + k]), v[6 + k]);
+                it.bmax[k] = std::fmax(std::fmax(v[k], v[3 + k]), v[6 + k]);
+                it.centroid[k] = (v[k] + v[3 + k] + v[6 + k]) / 3.0;
+            }
+            it.id = (int32_t)i;
+        }
+        out.blas.push_back(build_tree(std::move(items)));
+        out.verts64.insert(out.verts64.end(), mesh.vertices, mesh.vertices + mesh.n_triangles * 9);
+    }
+
+    // ---- scene-level tree (scene/mod.rs:699-700)
+    std::vector<BuildItem> top((size_t)scene.n_shapes);
+    for (uint32_t i = 0; i < scene.n_shapes; ++i) {
+        const RtShape &s = scene.shapes[i];
+        if (s.type == RT_SHAPE_INSTANCE) {
+            if (s.proto < 0 || (uint32_t)s.proto >= scene.n_protos) return "instance refers to a missing prototype";
+            const RtShape &p = scene.protos[s.proto];
+            if (p.type == RT_SHAPE_INSTANCE) return "an instanced shape can not be type instance";
+            if (p.type == RT_SHAPE_MESH && (p.mesh < 0 || (uint32_t)p.mesh >= scene.n_meshes))
+                return "prototype refers to a missing mesh";
+        }
+        if (s.shader < 0 || (uint32_t)s.shader >= scene.n_shaders) return "shape refers to a missing shader";
+        if (!shape_bounds(scene, s, out.blas, top[i])) return "malformed shape";
+        top[i].id = (int32_t)i;
+    }
+    out.tlas = build_tree(std::move(top));
+
+    // ---- node array: scene-level tree first, then the meshes
+    out.tlas_root = emit_with_header(out.tlas, 0, out.nodes);
+    std::vector<int32_t> blas_root(scene.n_meshes);
+    int blas_depth = 0;
+    for (uint32_t m = 0; m < scene.n_meshes; ++m) {
+        blas_root[m] = emit_with_header(out.blas[m], (uint32_t)out.mesh_tri_base[m], out.nodes);
+        blas_depth = std::max(blas_depth, out.blas[m].inner_depth);
+    }
+    // pushes on one path: one per inner node with two live children, plus, when a
+    // mesh or instance is entered from a leaf, the rest of that leaf and the exit marker
+    out.stack_depth = out.tlas.inner_depth + 2 + blas_depth + 1;
+
+    // ---- triangles in leaf order
+    out.tris.resize((size_t)tri_total);
+    for (uint32_t m = 0; m < scene.n_meshes; ++m) {
+        const RtMesh &mesh = scene.meshes[m];
+        const Tree &t = out.blas[m];
+        for (size_t k = 0; k < t.order.size(); ++k) {
+            const int32_t orig = t.order[k];
+            const double *v = mesh.vertices + (size_t)orig * 9;
+            RtTri &tri = out.tris[(size_t)out.mesh_tri_base[m] + k];
+            for (int c = 0; c < 3; ++c) {
+                tri.a[c] = (float)v[c];
+                tri.ab[c] = (float)(v[c] - v[3 + c]);
+                tri.ac[c] = (float)(v[c] - v[6 + c]);
+            }
+            tri.orig = orig;
+            tri.mesh = (int32_t)m;
+            tri._pad = 0;
+        }
+    }
+
+    // ---- top-level primitives in leaf order
+    out.tprims.resize(out.tlas.order.size());
+    for (size_t k = 0; k < out.tlas.order.size(); ++k) {
+        const int32_t id = out.tlas.order[k];
+        const RtShape &s = scene.shapes[id];
+        RtTPrim &p = out.tprims[k];
+        std::memset(&p, 0, sizeof(p));
+        p.type = s.type;
+        p.shape_id = id;
+        p.blas_root = -1;
+        p.proto_type = -1;
+        if (s.type == RT_SHAPE_MESH) {
+            p.blas_root = blas_root[(size_t)s.mesh];
+        } else if (s.type == RT_SHAPE_INSTANCE) {
+            const RtShape &proto = scene.protos[s.proto];
+            p.proto_type = proto.type;
+            if (proto.type == RT_SHAPE_MESH) p.blas_root = blas_root[(size_t)proto.mesh];
+            else fill_payload(proto, p.f);
+        } else {
+            fill_payload(s, p.f);
+        }
+    }
+    return "";
+}
+
+}  // namespace rt

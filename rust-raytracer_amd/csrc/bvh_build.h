@@ -1,0 +1,49 @@
+// bvh_build.h -- host-side BVH construction with the reference's split rule and
+// flattening of a whole scene into the fp32 records of rt_device_types.h.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_scene.h"
+#include "rt_device_types.h"
+
+namespace rt {
+
+struct BuildItem {
+    double bmin[3], bmax[3], centroid[3];
+    int32_t id;
+};
+
+struct TreeNode {
+    double bmin[3], bmax[3];
+    int32_t left = -1, right = -1;  // indices into Tree::nodes, -1 in a leaf
+    uint32_t first = 0, count = 0;  // leaf: range of Tree::order
+};
+
+struct Tree {
+    std::vector<TreeNode> nodes;  // pre-order, root at 0
+    std::vector<int32_t> order;   // item ids in leaf order
+    int inner_depth = 0;          // most inner nodes on any root-to-leaf path
+};
+
+// BVHNode::new (geometry/bvh.rs:36-87) starting on the X axis (bvh.rs:136).
+Tree build_tree(std::vector<BuildItem> items);
+
+struct FlatScene {
+    std::vector<RtNode> nodes;
+    std::vector<RtTPrim> tprims;
+    std::vector<RtTri> tris;
+    std::vector<uint64_t> mesh_tri_base;  // first entry of `tris` / `verts64` triangle per mesh
+    std::vector<double> verts64;          // 9 doubles per triangle, FILE order, meshes concatenated
+    int32_t tlas_root = 0;                // header node of the scene-level tree
+    int stack_depth = 0;                  // traversal-stack entries a ray can need at most
+    Tree tlas;                            // kept for structural tests
+    std::vector<Tree> blas;
+};
+
+// Returns "" on success, else a message.
+std::string flatten_scene(const RtScene &scene, FlatScene &out);
+
+}  // namespace rt

@@ -1,0 +1,705 @@
+// rt_backend.hip -- gfx950 kernels of the wavefront pipeline and the C ABI
+// around them (include/rt_hip.h).  Built for MI355X only.
+//
+// Kernel shape, common to every queue-consuming stage: a fixed grid of
+// 256-thread blocks walks its queue with a grid-stride loop; the queue length
+// lives in device memory (written by the previous stage's wave-wide ballot
+// allocations), so no stage needs a host round trip to learn its size.
+// Traversal kernels keep a per-lane stack in LDS, laid out [entry][thread] so a
+// wave's accesses to one stack level fall on 64 consecutive dwords.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "bvh_build.h"
+#include "rt_error.h"
+#include "rt_pipeline.h"
+
+#define RT_BLOCK 256
+#define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
+
+namespace {
+
+// ------------------------------------------------------------------ device helpers
+
+struct LdsStack {
+    int32_t *base;  // &lds[threadIdx.x]
+    __device__ __forceinline__ void set(int i, int32_t v) { base[i * RT_BLOCK] = v; }
+    __device__ __forceinline__ int32_t get(int i) const { return base[i * RT_BLOCK]; }
+};
+
+// Reserves one slot per lane with `pred` set, using ONE atomic per wave: the
+// 64-bit ballot gives each lane its rank among the wave's appenders.  Must be
+// reached by every lane of the wave.
+__device__ __forceinline__ uint32_t wave_alloc(bool pred, uint32_t *counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0u;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + rank;
+}
+
+// ------------------------------------------------------------------ kernels
+
+__global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples) {
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n_samples; base += gridDim.x * RT_BLOCK) {
+        const uint32_t ls = base + threadIdx.x;
+        D3 o, d;
+        const bool live = ls < n_samples && raygen_classify(S, B, ls, o, d);
+        const uint32_t slot = wave_alloc(live, &Q.counters[RT_CNT_RAYS0]);
+        if (live) queue_write_ray(Q, 0, slot, o, d, (int32_t)ls, -1, -1);
+    }
+}
+
+template <bool ORDERED, bool EXACT>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuffers Q, int bounce) {
+    extern __shared__ int32_t lds[];
+    LdsStack stk{lds + threadIdx.x};
+    const uint32_t count = Q.counters[RT_CNT_RAYS0 + bounce];
+    for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < count; idx += gridDim.x * RT_BLOCK)
+        trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, bounce, idx, stk);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce) {
+    const uint32_t count = Q.counters[RT_CNT_RAYS0 + bounce];
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < count; base += gridDim.x * RT_BLOCK) {
+        const uint32_t idx = base + threadIdx.x;
+        ShadeTmp tmp;
+        const int act = idx < count ? shade_classify(S, Q, B, ids, bounce, idx, tmp) : RT_ACT_NONE;
+        const uint32_t mslot = wave_alloc(act == RT_ACT_MIRROR, &Q.counters[RT_CNT_RAYS0 + bounce + 1]);
+        const uint32_t lslot = wave_alloc(act == RT_ACT_LIGHTS, &Q.counters[RT_CNT_SHADE]);
+        if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, mslot, tmp);
+        if (act == RT_ACT_LIGHTS) shade_commit_lights(Q, lslot, tmp);
+    }
+}
+
+template <bool ORDERED, bool ANYHIT, bool EXACT>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(RtSceneView S, RtBuffers Q) {
+    extern __shared__ int32_t lds[];
+    LdsStack stk{lds + threadIdx.x};
+    const uint32_t entries = Q.counters[RT_CNT_SHADE];
+    const uint64_t total = (uint64_t)entries * (uint32_t)S.n_point_lights;
+    // consecutive lanes = neighbouring hit points aiming at the SAME light
+    for (uint64_t w = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; w < total; w += (uint64_t)gridDim.x * RT_BLOCK)
+        trace_shadow_body<LdsStack, ORDERED, ANYHIT, EXACT>(S, Q, (uint32_t)(w / entries), (uint32_t)(w % entries), stk);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids) {
+    const uint32_t entries = Q.counters[RT_CNT_SHADE];
+    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < entries; e += gridDim.x * RT_BLOCK)
+        accumulate_body(S, Q, B, ids, e);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(RtBuffers Q, RtBatch B, float *fb) {
+    for (uint32_t lp = blockIdx.x * RT_BLOCK + threadIdx.x; lp < B.n_pixels; lp += gridDim.x * RT_BLOCK)
+        resolve_body(Q, B, lp, fb);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_fill_i32(int32_t *p, size_t n, int32_t v) {
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK) p[i] = v;
+}
+
+// BVH::closest_hit on caller-supplied rays (rt_trace_rays).
+template <bool ORDERED, bool EXACT>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace_user(RtSceneView S, uint64_t n, const double *o, const double *d, const double *tmin, const double *tmax,
+             float *t_out, int32_t *shape_out, int32_t *tri_out, uint32_t *overflow) {
+    extern __shared__ int32_t lds[];
+    LdsStack stk{lds + threadIdx.x};
+    for (uint64_t r = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (uint64_t)gridDim.x * RT_BLOCK) {
+        HitF hit;
+        const bool ok = trace_ray<LdsStack, ORDERED, false, EXACT>(
+            S, D3{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, D3{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]}, tmin[r], tmax[r],
+            -1, -1, stk, S.stack_depth, hit);
+        if (!ok) *overflow = 1;
+        t_out[r] = hit.t;
+        shape_out[r] = hit.shape;
+        tri_out[r] = tri_file_index(S, hit.tri);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+#define RT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return rt::set_error(RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dev_upload(const std::vector<T> &v, T **out) {
+    *out = nullptr;
+    if (v.empty()) return RT_OK;
+    RT_HIP(hipMalloc((void **)out, v.size() * sizeof(T)));
+    RT_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+}  // namespace
+
+struct RtBackend {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // batch buffers, grown on demand
+    RtBuffers buf{};
+    std::vector<void *> buf_allocs;
+    uint32_t buf_capacity = 0;
+    uint32_t buf_point_lights = 0;
+    // tile list of the last partition
+    int32_t *tile_list = nullptr;
+    std::vector<int32_t> tile_list_host;
+    uint32_t tile_key[6] = {0, 0, 0, 0, 0, 0};
+    // scratch framebuffer for rt_render
+    float *fb = nullptr;
+    size_t fb_floats = 0;
+};
+
+struct RtDeviceScene {
+    RtBackend *backend = nullptr;
+    RtSceneView view{};
+    std::vector<void *> allocs;
+    uint32_t width = 0, height = 0;
+    uint32_t n_point_lights = 0;
+    bool has_mirror = false;
+    bool has_lit = false;
+};
+
+namespace {
+
+void free_all(std::vector<void *> &v) {
+    for (void *p : v)
+        if (p) (void)hipFree(p);
+    v.clear();
+}
+
+template <typename T>
+int alloc_into(std::vector<void *> &owner, T **out, size_t count) {
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    owner.push_back(p);
+    *out = (T *)p;
+    return RT_OK;
+}
+
+int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
+    if (be->buf_capacity >= capacity && be->buf_point_lights >= n_point_lights) return RT_OK;
+    free_all(be->buf_allocs);
+    be->buf_capacity = 0;
+    RtBuffers &Q = be->buf;
+    std::memset(&Q, 0, sizeof(Q));
+    const size_t cap = capacity;
+    const size_t npl = std::max<uint32_t>(n_point_lights, 1);
+    int rc;
+    for (int w = 0; w < 2; ++w) {
+        for (int k = 0; k < 3; ++k) {
+            if ((rc = alloc_into(be->buf_allocs, &Q.q_o[w][k], cap))) return rc;
+            if ((rc = alloc_into(be->buf_allocs, &Q.q_d[w][k], cap))) return rc;
+        }
+        if ((rc = alloc_into(be->buf_allocs, &Q.q_sample[w], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.q_org_shape[w], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.q_org_tri[w], cap))) return rc;
+    }
+    if ((rc = alloc_into(be->buf_allocs, &Q.h_t, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.h_shape, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.h_tri, cap))) return rc;
+    for (int k = 0; k < 3; ++k) {
+        if ((rc = alloc_into(be->buf_allocs, &Q.s_p[k], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.s_n[k], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.s_d[k], cap))) return rc;
+    }
+    if ((rc = alloc_into(be->buf_allocs, &Q.s_sample, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.s_shape, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.s_tri, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.occ_shape, cap * npl))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.occ_tri, cap * npl))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.color, cap * 3))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.counters, (size_t)RT_CNT_SIZE))) return rc;
+    Q.capacity = capacity;
+    be->buf_capacity = capacity;
+    be->buf_point_lights = n_point_lights;
+    return RT_OK;
+}
+
+uint32_t grid_for(uint64_t work) {
+    const uint64_t blocks = (work + RT_BLOCK - 1) / RT_BLOCK;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, RT_MAX_GRID));
+}
+
+// Tiles owned by `part` of `parts`: tile k in tile-row r belongs to (k + r) % parts.
+void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t parts, std::vector<int32_t> &out) {
+    out.clear();
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+            const uint32_t k = ty * tiles_x + tx;
+            if (parts <= 1 || (k + ty) % parts == part) out.push_back((int32_t)k);
+        }
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+    int klass;
+};
+
+struct Timing {
+    bool on = false;
+    std::vector<EventPair> pairs;
+    hipStream_t stream = nullptr;
+    int begin(int klass) {
+        if (!on) return 0;
+        EventPair p;
+        p.klass = klass;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+        (void)hipEventRecord(p.a, stream);
+        pairs.push_back(p);
+        return 0;
+    }
+    void end() {
+        if (on) (void)hipEventRecord(pairs.back().b, stream);
+    }
+    void collect(RtStats *st) {
+        for (auto &p : pairs) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                st->kernel_ms[p.klass] += ms;
+                st->kernel_launches[p.klass] += 1;
+            }
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        pairs.clear();
+    }
+};
+
+int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
+                hipStream_t stream, RtStats *stats) {
+    if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
+    if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
+    if (args->antialias_method != RT_AA_NORMAL)
+        return rt::set_error(RT_ERR_UNSUPPORTED,
+                             "jittered / random antialiasing draw from an OS-seeded RNG in the reference and have "
+                             "no reproducible definition");
+    const uint32_t n = args->sqrt_rays_per_pixel;
+    if (n == 0 || n > 255) return rt::set_error(RT_ERR_INVALID, "sqrt_rays_per_pixel must be in 1..255");
+    if (args->mode != RT_MODE_FAST && args->mode != RT_MODE_REFERENCE_ORDER)
+        return rt::set_error(RT_ERR_INVALID, "unknown traversal mode");
+    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const uint32_t W = ds->width, H = ds->height;
+    const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    const uint32_t spp = n * n;
+    const uint64_t tile_samples = (uint64_t)tw * th * spp;
+    if (tile_samples > (1ull << 30)) return rt::set_error(RT_ERR_INVALID, "tile too large");
+    if (ds->view.recursion_depth > 30) return rt::set_error(RT_ERR_INVALID, "recursion depth above 30");
+
+    RT_HIP(hipSetDevice(be->device));
+    if (!stream) stream = be->stream;
+
+    // ---- tile list (cached per partition)
+    const uint32_t key[6] = {W, H, tw, th, args->part_index, parts};
+    if (std::memcmp(key, be->tile_key, sizeof(key)) != 0 || !be->tile_list) {
+        owned_tiles(tiles_x, tiles_y, args->part_index, parts, be->tile_list_host);
+        if (be->tile_list) (void)hipFree(be->tile_list);
+        be->tile_list = nullptr;
+        RT_HIP(hipMalloc((void **)&be->tile_list, std::max<size_t>(be->tile_list_host.size(), 1) * sizeof(int32_t)));
+        if (!be->tile_list_host.empty())
+            RT_HIP(hipMemcpy(be->tile_list, be->tile_list_host.data(), be->tile_list_host.size() * sizeof(int32_t),
+                             hipMemcpyHostToDevice));
+        std::memcpy(be->tile_key, key, sizeof(key));
+    }
+    const uint32_t n_slots = (uint32_t)be->tile_list_host.size();
+
+    // ---- batch size
+    uint64_t max_batch = 16ull << 20;
+    if (const char *e = std::getenv("RT_BATCH_SAMPLES")) max_batch = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    const uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / tile_samples);
+    const uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
+    const uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
+    int rc = ensure_buffers(be, capacity, ds->n_point_lights);
+    if (rc) return rc;
+    const RtBuffers Q = be->buf;
+    const RtSceneView &S = ds->view;
+
+    RtIdOut io{};
+    if (ids) {
+        io.primary_shape = ids->primary_shape; io.primary_tri = ids->primary_tri;
+        io.final_shape = ids->final_shape; io.final_tri = ids->final_tri; io.bounces = ids->bounces;
+        io.shadow_shape = ids->shadow_shape; io.shadow_tri = ids->shadow_tri;
+        const size_t total = (size_t)W * H * spp * ds->n_point_lights;
+        if (io.shadow_shape && total) hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(total)), dim3(RT_BLOCK), 0, stream, io.shadow_shape, total, -2);
+        if (io.shadow_tri && total) hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(total)), dim3(RT_BLOCK), 0, stream, io.shadow_tri, total, -2);
+    }
+
+    Timing tm;
+    tm.on = stats != nullptr;
+    tm.stream = stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        RT_HIP(hipEventCreate(&ev0));
+        RT_HIP(hipEventCreate(&ev1));
+        RT_HIP(hipEventRecord(ev0, stream));
+    }
+    const size_t lds_bytes = (size_t)std::max(S.stack_depth, 1) * RT_BLOCK * sizeof(int32_t);
+    if (lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
+    const bool ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
+    const int max_bounce = ds->has_mirror ? S.recursion_depth : 0;
+    std::vector<uint32_t> host_counters;
+
+    for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
+        const uint32_t slots = std::min(batch_slots, n_slots - slot0);
+        RtBatch B{};
+        B.tile_list = be->tile_list;
+        B.slot0 = slot0;
+        B.n_pixels = slots * tw * th;
+        B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x;
+        B.width = W; B.height = H;
+        B.n = n;
+        B.compact_fb = parts > 1 ? 1u : 0u;
+        const uint32_t n_samples = B.n_pixels * spp;
+
+        RT_HIP(hipMemsetAsync(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t), stream));
+        if (tm.begin(RT_K_RAYGEN)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_samples)), dim3(RT_BLOCK), 0, stream, S, Q, B, n_samples);
+        tm.end();
+
+        for (int bounce = 0; bounce <= max_bounce; ++bounce) {
+            // queue of bounce b holds at most n_samples rays; later bounces are usually far shorter,
+            // and the grid-stride kernels cost little when their queue is empty
+            const uint32_t g = grid_for(n_samples);
+            if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            if (ref_order)
+                hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, bounce);
+            else
+                hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, bounce);
+            tm.end();
+            if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            hipLaunchKernelGGL(k_shade, dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce);
+            tm.end();
+        }
+        if (ds->has_lit) {
+            const uint64_t shadow_work = (uint64_t)n_samples * ds->n_point_lights;
+            if (!S.disable_shadows && ds->n_point_lights > 0) {
+                if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                if (ref_order)
+                    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(grid_for(shadow_work)), dim3(RT_BLOCK), lds_bytes, stream, S, Q);
+                else
+                    hipLaunchKernelGGL((k_trace_shadow<true, true, false>), dim3(grid_for(shadow_work)), dim3(RT_BLOCK), lds_bytes, stream, S, Q);
+                tm.end();
+            }
+            if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(n_samples)), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
+            tm.end();
+        }
+        if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(B.n_pixels)), dim3(RT_BLOCK), 0, stream, Q, B, fb_dev);
+        tm.end();
+
+        if (stats) {
+            // counters must be read before the next batch clears them
+            const size_t at = host_counters.size();
+            host_counters.resize(at + RT_CNT_SIZE);
+            RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipStreamSynchronize(stream));
+        }
+    }
+    RT_HIP(hipGetLastError());
+    if (stats) {
+        RT_HIP(hipEventRecord(ev1, stream));
+        RT_HIP(hipStreamSynchronize(stream));
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        stats->render_ms = ms;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        tm.collect(stats);
+        bool overflow = false;
+        for (size_t at = 0; at < host_counters.size(); at += RT_CNT_SIZE) {
+            const uint32_t *c = host_counters.data() + at;
+            stats->primary_rays += c[RT_CNT_RAYS0];
+            for (int b = 1; b <= max_bounce && b < 32; ++b) stats->secondary_rays += c[RT_CNT_RAYS0 + b];
+            stats->shaded_hits += c[RT_CNT_SHADE];
+            if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_SHADE] * ds->n_point_lights;
+            overflow = overflow || c[RT_CNT_OVERFLOW] != 0;
+        }
+        if (overflow) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" const char *rt_last_error(void) { return rt::last_error_slot().c_str(); }
+
+extern "C" int rt_backend_create(int device_ordinal, RtBackend **backend_out) {
+    if (!backend_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+    *backend_out = nullptr;
+    int count = 0;
+    RT_HIP(hipGetDeviceCount(&count));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return rt::set_error(RT_ERR_DEVICE, "no HIP device with ordinal " + std::to_string(device_ordinal));
+    RT_HIP(hipSetDevice(device_ordinal));
+    RtBackend *be = new RtBackend();
+    be->device = device_ordinal;
+    hipError_t e = hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete be;
+        return rt::set_error(RT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *backend_out = be;
+    return RT_OK;
+}
+
+extern "C" void rt_backend_destroy(RtBackend *be) {
+    if (!be) return;
+    (void)hipSetDevice(be->device);
+    if (be->stream) (void)hipStreamSynchronize(be->stream);
+    free_all(be->buf_allocs);
+    if (be->tile_list) (void)hipFree(be->tile_list);
+    if (be->fb) (void)hipFree(be->fb);
+    if (be->stream) (void)hipStreamDestroy(be->stream);
+    delete be;
+}
+
+extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScene **out) {
+    if (!be || !scene || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    for (uint32_t i = 0; i < scene->n_shaders; ++i)
+        if (scene->shaders[i].type == RT_SHADER_GGX_MIRROR) {
+            // only an error if a shape actually uses it
+            for (uint32_t s = 0; s < scene->n_shapes; ++s)
+                if (scene->shapes[s].shader == (int32_t)i)
+                    return rt::set_error(RT_ERR_UNSUPPORTED,
+                                         "GGXMirror samples an OS-seeded RNG in the reference and has no "
+                                         "reproducible definition");
+        }
+    rt::FlatScene flat;
+    const std::string err = rt::flatten_scene(*scene, flat);
+    if (!err.empty()) return rt::set_error(RT_ERR_INVALID, err);
+    RT_HIP(hipSetDevice(be->device));
+
+    RtDeviceScene *ds = new RtDeviceScene();
+    ds->backend = be;
+    auto fail = [&](int rc) {
+        free_all(ds->allocs);
+        delete ds;
+        return rc;
+    };
+    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+        void *p = nullptr;
+        RT_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        ds->allocs.push_back(p);
+        if (bytes) RT_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        *dst = p;
+        return RT_OK;
+    };
+    RtSceneView &V = ds->view;
+    std::vector<int32_t> point_lights;
+    for (uint32_t i = 0; i < scene->n_lights; ++i)
+        if (scene->lights[i].type == RT_LIGHT_POINT) point_lights.push_back((int32_t)i);
+    int rc;
+    if ((rc = up(flat.nodes.data(), flat.nodes.size() * sizeof(RtNode), (const void **)&V.nodes))) return fail(rc);
+    if ((rc = up(flat.tprims.data(), flat.tprims.size() * sizeof(RtTPrim), (const void **)&V.tprims))) return fail(rc);
+    if ((rc = up(flat.tris.data(), flat.tris.size() * sizeof(RtTri), (const void **)&V.tris))) return fail(rc);
+    if ((rc = up(scene->shapes, scene->n_shapes * sizeof(RtShape), (const void **)&V.shapes))) return fail(rc);
+    if ((rc = up(scene->protos, scene->n_protos * sizeof(RtShape), (const void **)&V.protos))) return fail(rc);
+    if ((rc = up(flat.verts64.data(), flat.verts64.size() * sizeof(double), (const void **)&V.verts64))) return fail(rc);
+    if ((rc = up(flat.mesh_tri_base.data(), flat.mesh_tri_base.size() * sizeof(uint64_t), (const void **)&V.mesh_tri_base))) return fail(rc);
+    if ((rc = up(scene->shaders, scene->n_shaders * sizeof(RtShader), (const void **)&V.shaders))) return fail(rc);
+    if ((rc = up(scene->lights, scene->n_lights * sizeof(RtLight), (const void **)&V.lights))) return fail(rc);
+    if ((rc = up(point_lights.data(), point_lights.size() * sizeof(int32_t), (const void **)&V.point_lights))) return fail(rc);
+    V.camera = scene->camera;
+    std::memcpy(V.background, scene->background, sizeof(V.background));
+    V.n_lights = (int32_t)scene->n_lights;
+    V.n_point_lights = (int32_t)point_lights.size();
+    V.tlas_root = flat.tlas_root;
+    V.recursion_depth = scene->recursion_depth;
+    V.disable_shadows = scene->disable_shadows;
+    V.stack_depth = flat.stack_depth;
+    ds->width = scene->image_width;
+    ds->height = scene->image_height;
+    ds->n_point_lights = (uint32_t)point_lights.size();
+    for (uint32_t s = 0; s < scene->n_shapes; ++s) {
+        const int32_t t = scene->shaders[scene->shapes[s].shader].type;
+        ds->has_mirror = ds->has_mirror || t == RT_SHADER_PERFECT_MIRROR;
+        ds->has_lit = ds->has_lit || t == RT_SHADER_LAMBERTIAN || t == RT_SHADER_BLINN_PHONG;
+    }
+    *out = ds;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_free(RtDeviceScene *ds) {
+    if (!ds) return;
+    if (ds->backend) {
+        (void)hipSetDevice(ds->backend->device);
+        if (ds->backend->stream) (void)hipStreamSynchronize(ds->backend->stream);
+    }
+    free_all(ds->allocs);
+    delete ds;
+}
+
+extern "C" uint32_t rt_scene_point_light_count(const RtDeviceScene *ds) { return ds ? ds->n_point_lights : 0; }
+
+extern "C" int rt_render_device(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_dev,
+                                const RtRayIds *ids_dev, void *hip_stream, RtStats *stats_out) {
+    return render_impl(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, stats_out);
+}
+
+extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb,
+                         const RtRayIds *ids_host, RtStats *stats_out) {
+    if (!be || !ds || !args || !fb_rgb) return rt::set_error(RT_ERR_INVALID, "null argument");
+    RT_HIP(hipSetDevice(be->device));
+    const size_t W = ds->width, H = ds->height;
+    const size_t n = args->sqrt_rays_per_pixel;
+    const size_t samples = W * H * n * n;
+    const size_t fb_floats = W * H * 3;
+    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const uint32_t tiles_x = ((uint32_t)W + tw - 1) / tw, tiles_y = ((uint32_t)H + th - 1) / th;
+    // a partitioned render lands tile-major (edge tiles padded), so size for whole tiles
+    const size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
+    if (be->fb_floats < dev_floats) {
+        if (be->fb) (void)hipFree(be->fb);
+        be->fb = nullptr;
+        be->fb_floats = 0;
+        RT_HIP(hipMalloc((void **)&be->fb, dev_floats * sizeof(float)));
+        be->fb_floats = dev_floats;
+    }
+    RT_HIP(hipMemsetAsync(be->fb, 0, fb_floats * sizeof(float), be->stream));
+
+    // device mirrors of the requested id arrays
+    std::vector<void *> tmp;
+    RtRayIds dev{};
+    struct Copy {
+        int32_t *host, *dev;
+        size_t count;
+    };
+    std::vector<Copy> copies;
+    auto cleanup = [&]() { free_all(tmp); };
+    if (ids_host) {
+        const size_t npl = ds->n_point_lights;
+        struct Want {
+            int32_t *host;
+            int32_t **dev;
+            size_t count;
+        } wants[] = {{ids_host->primary_shape, &dev.primary_shape, samples}, {ids_host->primary_tri, &dev.primary_tri, samples},
+                     {ids_host->final_shape, &dev.final_shape, samples},     {ids_host->final_tri, &dev.final_tri, samples},
+                     {ids_host->bounces, &dev.bounces, samples},             {ids_host->shadow_shape, &dev.shadow_shape, samples * npl},
+                     {ids_host->shadow_tri, &dev.shadow_tri, samples * npl}};
+        for (auto &w : wants) {
+            if (!w.host || w.count == 0) continue;
+            void *p = nullptr;
+            hipError_t e = hipMalloc(&p, w.count * sizeof(int32_t));
+            if (e != hipSuccess) {
+                cleanup();
+                return rt::set_error(RT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+            }
+            tmp.push_back(p);
+            *w.dev = (int32_t *)p;
+            (void)hipMemsetAsync(p, 0xFF, w.count * sizeof(int32_t), be->stream);  // -1
+            copies.push_back({w.host, (int32_t *)p, w.count});
+        }
+    }
+    const RtRenderArgs &a = *args;
+    int rc;
+    RtStats local_stats;
+    rc = render_impl(be, ds, &a, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out ? stats_out : &local_stats);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    if (parts > 1) {
+        // compact tile-major -> full layout on the host, owned pixels only
+        std::vector<float> compact(be->tile_list_host.size() * tw * th * 3);
+        if (!compact.empty()) {
+            hipError_t e = hipMemcpy(compact.data(), be->fb, compact.size() * sizeof(float), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                cleanup();
+                return rt::set_error(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+            }
+        }
+        for (size_t s = 0; s < be->tile_list_host.size(); ++s) {
+            const uint32_t tile = (uint32_t)be->tile_list_host[s];
+            for (uint32_t r = 0; r < tw * th; ++r) {
+                const uint32_t i = (tile % tiles_x) * tw + r % tw, j = (tile / tiles_x) * th + r / tw;
+                if (i >= W || j >= H) continue;
+                const size_t src = (s * tw * th + r) * 3;
+                std::memcpy(fb_rgb + (i + (size_t)j * W) * 3, compact.data() + src, 3 * sizeof(float));
+            }
+        }
+    } else {
+        hipError_t e = hipMemcpy(fb_rgb, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            cleanup();
+            return rt::set_error(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+    }
+    for (auto &c : copies) {
+        hipError_t e = hipMemcpy(c.host, c.dev, c.count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            cleanup();
+            return rt::set_error(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+    }
+    cleanup();
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays(RtBackend *be, const RtDeviceScene *ds, uint64_t n, const double *origins,
+                             const double *directions, const double *tmin, const double *tmax, int32_t mode,
+                             float *t_out, int32_t *shape_out, int32_t *tri_out) {
+    if (!be || !ds || !origins || !directions || !tmin || !tmax || !t_out || !shape_out || !tri_out)
+        return rt::set_error(RT_ERR_INVALID, "null argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(be->device));
+    std::vector<void *> tmp;
+    double *d_o = nullptr, *d_d = nullptr, *d_tmin = nullptr, *d_tmax = nullptr;
+    float *d_t = nullptr;
+    int32_t *d_shape = nullptr, *d_tri = nullptr;
+    uint32_t *d_over = nullptr;
+    int rc;
+    auto bail = [&](int code) {
+        free_all(tmp);
+        return code;
+    };
+    if ((rc = alloc_into(tmp, &d_o, n * 3)) || (rc = alloc_into(tmp, &d_d, n * 3)) || (rc = alloc_into(tmp, &d_tmin, n)) ||
+        (rc = alloc_into(tmp, &d_tmax, n)) || (rc = alloc_into(tmp, &d_t, n)) || (rc = alloc_into(tmp, &d_shape, n)) ||
+        (rc = alloc_into(tmp, &d_tri, n)) || (rc = alloc_into(tmp, &d_over, 1)))
+        return bail(rc);
+    if (hipMemcpy(d_o, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_d, directions, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_tmin, tmin, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_tmax, tmax, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(d_over, 0, sizeof(uint32_t)) != hipSuccess)
+        return bail(rt::set_error(RT_ERR_DEVICE, "hipMemcpy to device failed"));
+    const size_t lds_bytes = (size_t)std::max(ds->view.stack_depth, 1) * RT_BLOCK * sizeof(int32_t);
+    if (lds_bytes > 64 * 1024) return bail(rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack"));
+    if (mode == RT_MODE_REFERENCE_ORDER)
+        hipLaunchKernelGGL((k_trace_user<false, true>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
+    else
+        hipLaunchKernelGGL((k_trace_user<true, false>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
+    uint32_t over = 0;
+    if (hipStreamSynchronize(be->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
+        hipMemcpy(t_out, d_t, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(shape_out, d_shape, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(tri_out, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&over, d_over, sizeof(over), hipMemcpyDeviceToHost) != hipSuccess)
+        return bail(rt::set_error(RT_ERR_DEVICE, "trace kernel or copy back failed"));
+    free_all(tmp);
+    if (over) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
+    return RT_OK;
+}

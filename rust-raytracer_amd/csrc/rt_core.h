@@ -1,0 +1,570 @@
+// rt_core.h -- per-ray device functions of the render backend: fp32 BVH
+// traversal and primitive intersection, the f64 "exact" primitive routines used
+// once per ray, camera rays and shading.
+//
+// Precision split (what runs in which type, and why):
+//   * Everything that runs once per BVH node or per candidate primitive is fp32
+//     and follows the reference's formulas operation by operation
+//     (geometry/bbox.rs:76-125, sphere.rs:58-89, triangle.rs:66-118).
+//   * Everything that runs once per RAY is f64 and is the reference's own
+//     arithmetic: camera ray generation, the hit point / normal of the winning
+//     primitive, mirror and shadow ray set-up, the instance transforms, and the
+//     test of a secondary ray against the primitive it starts on.  CDNA4's f64
+//     vector rate is half its f32 rate, so this costs a few percent, and it keeps
+//     fp32 error from accumulating along a chain of bounces: each new ray starts
+//     from the same f64 point the reference would use.
+//   * A secondary ray starts ON a primitive; whether it re-hits that primitive is
+//     decided by t ~ 1e-16 against t_min = 1e-6 in the reference.  fp32 cannot
+//     resolve that, so traversal skips the origin primitive and the caller tests
+//     it separately in f64 (exact_prim_hit) -- closest-hit is order independent.
+//
+// The functions are written so that they also compile as ordinary C++ for a
+// host-side test build (no HIP intrinsics in this file).
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/rt_scene.h"
+#include "rt_device_types.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+typedef float4 rt_f4;
+#else
+#define RT_HD inline
+struct alignas(16) rt_f4 {
+    float x, y, z, w;
+};
+#endif
+
+#ifndef RT_ORIGIN_LO
+#define RT_ORIGIN_LO 1  // carry the fp32 rounding residual of ray origins (o = hi + lo)
+#endif
+
+#define RT_VERY_SMALL_NUMBER 1e-6 /* prelude.rs:42 */
+
+// Everything a kernel needs to know about the uploaded scene; passed by value.
+struct RtSceneView {
+    const rt_f4 *nodes;   // 4 per RtNode
+    const rt_f4 *tprims;  // 4 per RtTPrim
+    const rt_f4 *tris;    // 3 per RtTri
+    const RtShape *shapes;
+    const RtShape *protos;
+    const double *verts64;          // 9 doubles per mesh triangle, file order, meshes concatenated
+    const uint64_t *mesh_tri_base;  // first triangle of each mesh in verts64 / tris
+    const RtShader *shaders;
+    const RtLight *lights;
+    const int32_t *point_lights;    // indices into lights[] of the point lights, in order
+    RtCamera camera;
+    float background[3];
+    int32_t n_lights, n_point_lights;
+    int32_t tlas_root;
+    int32_t recursion_depth;
+    int32_t disable_shadows;
+    int32_t stack_depth;
+};
+
+// ---------------------------------------------------------------- small helpers
+
+RT_HD int32_t rt_as_int(float f) { return __builtin_bit_cast(int32_t, f); }
+RT_HD float rt_fmax(float a, float b) { return __builtin_fmaxf(a, b); }  // NaN-ignoring, like f64::max
+RT_HD float rt_fmin(float a, float b) { return __builtin_fminf(a, b); }
+RT_HD double rt_dmax(double a, double b) { return __builtin_fmax(a, b); }
+RT_HD double rt_dmin(double a, double b) { return __builtin_fmin(a, b); }
+
+struct D3 {
+    double x, y, z;
+};
+RT_HD D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+RT_HD D3 d3(const RtVec3 &v) { return D3{v.x, v.y, v.z}; }
+RT_HD D3 operator+(const D3 &a, const D3 &b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD D3 operator-(const D3 &a, const D3 &b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD D3 operator-(const D3 &a) { return D3{-a.x, -a.y, -a.z}; }
+RT_HD D3 operator*(const D3 &a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+RT_HD D3 operator/(const D3 &a, double s) { return D3{a.x / s, a.y / s, a.z / s}; }
+RT_HD double dot(const D3 &a, const D3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD D3 cross(const D3 &a, const D3 &b) {
+    return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RT_HD D3 normalize(const D3 &a) { return a / __builtin_sqrt(dot(a, a)); }
+
+// Matrix3::from_columns(&[c0, c1, c2]).determinant() -- the expression of the
+// reference's matrix library, used by triangle.rs:76-105.
+RT_HD double det3_columns(const D3 &c0, const D3 &c1, const D3 &c2) {
+    const double minor_m12_m23 = c1.y * c2.z - c1.z * c2.y;
+    const double minor_m11_m23 = c0.y * c2.z - c0.z * c2.y;
+    const double minor_m11_m22 = c0.y * c1.z - c0.z * c1.y;
+    return c0.x * minor_m12_m23 - c1.x * minor_m11_m23 + c2.x * minor_m11_m22;
+}
+RT_HD float det3_columns_f(float c0x, float c0y, float c0z, float c1x, float c1y, float c1z, float c2x,
+                           float c2y, float c2z) {
+    const float minor_m12_m23 = c1y * c2z - c1z * c2y;
+    const float minor_m11_m23 = c0y * c2z - c0z * c2y;
+    const float minor_m11_m22 = c0y * c1z - c0z * c1y;
+    return c0x * minor_m12_m23 - c1x * minor_m11_m23 + c2x * minor_m11_m22;
+}
+
+// Matrix4::transform_vector / transform_point on a row-major 4x4 (instance.rs:78-79, 89).
+RT_HD D3 transform_vector(const double *m, const D3 &v) {
+    D3 r;
+    r.x = (m[0] * v.x + m[1] * v.y) + m[2] * v.z;
+    r.y = (m[4] * v.x + m[5] * v.y) + m[6] * v.z;
+    r.z = (m[8] * v.x + m[9] * v.y) + m[10] * v.z;
+    return r;
+}
+RT_HD D3 transform_point(const double *m, const D3 &p) {
+    D3 r = transform_vector(m, p);
+    r = D3{r.x + m[3], r.y + m[7], r.z + m[11]};
+    const double n = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (n != 0.0) r = r / n;
+    return r;
+}
+
+// ---------------------------------------------------------------- f64 "exact" primitives
+
+// BBox::hit, geometry/bbox.rs:76-125, sequential form.
+RT_HD bool slab_f64(const D3 &mn, const D3 &mx, const D3 &o, const D3 &d, double tmin, double tmax, double &t_out) {
+    double tn = (mn.x - o.x) / d.x, tf = (mx.x - o.x) / d.x;
+    if (1.0 / d.x < 0.0) { double s = tn; tn = tf; tf = s; }
+    if (tn >= tf || tn >= tmax || tf <= tmin) return false;
+    tmax = rt_dmin(tmax, tf);
+    tmin = rt_dmax(tmin, tn);
+    tn = (mn.y - o.y) / d.y; tf = (mx.y - o.y) / d.y;
+    if (1.0 / d.y < 0.0) { double s = tn; tn = tf; tf = s; }
+    if (tn >= tf || tn >= tmax || tf <= tmin) return false;
+    tmax = rt_dmin(tmax, tf);
+    tmin = rt_dmax(tmin, tn);
+    tn = (mn.z - o.z) / d.z; tf = (mx.z - o.z) / d.z;
+    if (1.0 / d.z < 0.0) { double s = tn; tn = tf; tf = s; }
+    if (tn >= tf || tn >= tmax || tf <= tmin) return false;
+    t_out = rt_dmax(tn, tmin);
+    return true;
+}
+
+// Sphere::closest_hit, sphere.rs:58-84 (the t selection).  `forced` returns the
+// nearest admissible root even when the f64 test itself says "miss".
+RT_HD bool sphere_f64(const D3 &c, double r, const D3 &o, const D3 &d, double tmin, double tmax, bool forced,
+                      double &t_out) {
+    const D3 oc = o - c;
+    const double cd = dot(oc, d);
+    double disc = cd * cd - dot(d, d) * (dot(oc, oc) - r * r);
+    if (disc < 0.0) {
+        if (!forced) return false;
+        disc = 0.0;
+    }
+    const double num = -dot(oc, d), den = dot(d, d);
+    const double t1 = (num - __builtin_sqrt(disc)) / den;
+    const double t2 = (num + __builtin_sqrt(disc)) / den;
+    const bool in1 = tmin <= t1 && t1 < tmax, in2 = tmin <= t2 && t2 < tmax;
+    if (in1 && in2) t_out = rt_dmin(t1, t2);
+    else if (in1) t_out = t1;
+    else if (in2) t_out = t2;
+    else {
+        if (!forced) return false;
+        t_out = t1 >= tmin ? t1 : t2;
+    }
+    return true;
+}
+
+// Triangle::closest_hit, triangle.rs:66-110.
+RT_HD bool triangle_f64(const D3 &a, const D3 &b, const D3 &c, const D3 &o, const D3 &d, double tmin, double tmax,
+                        bool forced, double &t_out) {
+    const D3 ab = a - b, ac = a - c, ao = a - o;
+    const double det_a = det3_columns(ab, ac, d);
+    if (__builtin_fabs(det_a) < 2.220446049250313e-16 && !forced) return false;
+    const double t = det3_columns(ab, ac, ao) / det_a;
+    t_out = t;
+    if (forced) return true;
+    if (t < tmin || t > tmax) return false;
+    const double gamma = det3_columns(ab, ao, d) / det_a;
+    if (gamma < 0.0 || gamma > 1.0) return false;
+    const double beta = det3_columns(ao, ac, d) / det_a;
+    if (beta < 0.0 || beta > 1.0 - gamma) return false;
+    return true;
+}
+
+// Cuboid::normal, cuboid.rs:24-39 (before normalisation).
+RT_HD D3 cuboid_normal(const D3 &mn, const D3 &mx, const D3 &p) {
+    const D3 centroid = (mn + mx) * 0.5;  // bbox.rs:18
+    const D3 extent = mx - mn;            // bbox.rs:19
+    const D3 pc = p - centroid;
+    const double dx = __builtin_fabs(pc.x / extent.x), dy = __builtin_fabs(pc.y / extent.y),
+                 dz = __builtin_fabs(pc.z / extent.z);
+    if (dx > dy && dx > dz) return D3{pc.x > 0.0 ? 1.0 : -1.0, 0.0, 0.0};
+    if (dy > dz) return D3{0.0, pc.y > 0.0 ? 1.0 : -1.0, 0.0};
+    return D3{0.0, 0.0, pc.z > 0.0 ? 1.0 : -1.0};
+}
+
+// Intersects ONE identified primitive with a ray, entirely in f64 with the
+// reference's formulas, instance transform included (instance.rs:75-94).
+//   shape_id : index into RtScene.shapes;  gtri : global leaf-order triangle index or -1.
+//   forced   : the caller already knows (from fp32 traversal) that this primitive
+//              is the winner and only wants t and the normal.
+// Returns true on a hit; t_out and, if non-null, the world-space unit normal.
+RT_HD bool exact_prim_hit(const RtSceneView &S, int32_t shape_id, int32_t gtri, D3 o, D3 d, double tmin, double tmax,
+                          bool forced, double t_fallback, double &t_out, D3 *normal_out) {
+    const RtShape *sh = &S.shapes[shape_id];
+    const RtShape *inst = nullptr;
+    if (sh->type == RT_SHAPE_INSTANCE) {
+        inst = sh;
+        o = transform_point(inst->inv_transform, o);
+        d = transform_vector(inst->inv_transform, d);
+        sh = &S.protos[inst->proto];
+    }
+    D3 n = D3{0.0, 0.0, 0.0};
+    bool got = false;
+    double t = t_fallback;
+    switch (sh->type) {
+    case RT_SHAPE_SPHERE: {
+        const D3 c = d3(sh->p0);
+        got = sphere_f64(c, sh->radius, o, d, tmin, tmax, forced, t);
+        if (got && normal_out) n = normalize((o + d * t) - c);  // sphere.rs:86
+        break;
+    }
+    case RT_SHAPE_BOX: {
+        const D3 mn = d3(sh->p0), mx = d3(sh->p1);
+        got = slab_f64(mn, mx, o, d, tmin, tmax, t);
+        if (!got && forced) {
+            t = t_fallback;
+            got = true;
+        }
+        if (got && normal_out) n = normalize(cuboid_normal(mn, mx, o + d * t));  // cuboid.rs:66
+        break;
+    }
+    case RT_SHAPE_TRIANGLE: {
+        const D3 a = d3(sh->p0), b = d3(sh->p1), c = d3(sh->p2);
+        got = triangle_f64(a, b, c, o, d, tmin, tmax, forced, t);
+        if (got && normal_out) n = normalize(cross(b - a, c - a));  // triangle.rs:22
+        break;
+    }
+    case RT_SHAPE_MESH: {
+        if (gtri < 0) break;
+        const RtTri *rec = reinterpret_cast<const RtTri *>(S.tris) + gtri;
+        const double *v = S.verts64 + (S.mesh_tri_base[rec->mesh] + (uint64_t)rec->orig) * 9;
+        const D3 a = d3(v[0], v[1], v[2]), b = d3(v[3], v[4], v[5]), c = d3(v[6], v[7], v[8]);
+        got = triangle_f64(a, b, c, o, d, tmin, tmax, forced, t);
+        if (got && normal_out) n = normalize(cross(b - a, c - a));
+        break;
+    }
+    default: break;
+    }
+    if (!got) return false;
+    t_out = t;
+    if (normal_out) {
+        if (inst) n = normalize(transform_vector(inst->normal_matrix, n));  // instance.rs:89-90
+        *normal_out = n;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- fp32 traversal
+
+struct RayF {
+    float ox, oy, oz;  // origin, rounded to fp32
+#if RT_ORIGIN_LO
+    float lx, ly, lz;  // what the rounding dropped
+#endif
+    float dx, dy, dz;
+    float ix, iy, iz;  // 1 / d (only used by the fast node test)
+    bool nx, ny, nz;   // 1/d < 0, the reference's swap condition (bbox.rs:84)
+};
+
+RT_HD void ray_from_f64(const D3 &o, const D3 &d, RayF &r) {
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+#if RT_ORIGIN_LO
+    r.lx = (float)(o.x - (double)r.ox); r.ly = (float)(o.y - (double)r.oy); r.lz = (float)(o.z - (double)r.oz);
+#endif
+    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    r.nx = r.ix < 0.0f; r.ny = r.iy < 0.0f; r.nz = r.iz < 0.0f;
+}
+
+// p - origin, using the residual when it is carried
+#if RT_ORIGIN_LO
+#define RT_REL(p, o, l) (((p) - (o)) - (l))
+#else
+#define RT_REL(p, o, l) ((p) - (o))
+#endif
+
+// BBox::hit (bbox.rs:76-125) in closed form.  The reference's three per-axis
+// stages reject exactly when  max(tn) >= min(tf)  or  max(tn) >= tmax  or
+// min(tf) <= tmin, with NaN (0/0) comparing false and ignored by min/max, and
+// it returns max(tn_z, tmin') = max(tmin, max(tn)).  EXACT uses true divisions
+// like the reference; otherwise the per-ray reciprocal.
+template <bool EXACT>
+RT_HD bool slab_f32(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayF &r, float tmin,
+                    float tmax, float &entry) {
+#if RT_ORIGIN_LO
+    const float ax = RT_REL(mnx, r.ox, r.lx), ay = RT_REL(mny, r.oy, r.ly), az = RT_REL(mnz, r.oz, r.lz);
+    const float bx = RT_REL(mxx, r.ox, r.lx), by = RT_REL(mxy, r.oy, r.ly), bz = RT_REL(mxz, r.oz, r.lz);
+#else
+    const float ax = mnx - r.ox, ay = mny - r.oy, az = mnz - r.oz;
+    const float bx = mxx - r.ox, by = mxy - r.oy, bz = mxz - r.oz;
+#endif
+    float t0x, t1x, t0y, t1y, t0z, t1z;
+    if (EXACT) {
+        t0x = ax / r.dx; t1x = bx / r.dx;
+        t0y = ay / r.dy; t1y = by / r.dy;
+        t0z = az / r.dz; t1z = bz / r.dz;
+    } else {
+        t0x = ax * r.ix; t1x = bx * r.ix;
+        t0y = ay * r.iy; t1y = by * r.iy;
+        t0z = az * r.iz; t1z = bz * r.iz;
+    }
+    const float tnx = r.nx ? t1x : t0x, tfx = r.nx ? t0x : t1x;
+    const float tny = r.ny ? t1y : t0y, tfy = r.ny ? t0y : t1y;
+    const float tnz = r.nz ? t1z : t0z, tfz = r.nz ? t0z : t1z;
+    // per-axis emptiness (tn_k >= tf_k) is part of max(tn) >= min(tf)
+    const float e = rt_fmax(rt_fmax(tnx, tny), tnz);
+    const float x = rt_fmin(rt_fmin(tfx, tfy), tfz);
+    if (e >= x || e >= tmax || x <= tmin) return false;
+    entry = rt_fmax(e, tmin);
+    return true;
+}
+
+struct HitF {
+    float t;        // in: upper bound of the search interval; out: t of the hit
+    int32_t shape;  // index into RtScene.shapes, -1 = nothing
+    int32_t tri;    // global leaf-order triangle index, -1 when not inside a mesh
+};
+
+// Sphere::closest_hit (sphere.rs:58-84) in fp32.
+//
+// The reference's discriminant  (oc.d)^2 - (d.d)(oc.oc - r^2)  subtracts two
+// numbers of size (|oc||d|)^2 to get one of size (r|d|)^2; in fp32 that loses
+// the silhouette of a small distant sphere (1e-4 of its samples at |oc|/r = 30).
+// By Lagrange's identity the same quantity is  (d.d) r^2 - |oc x d|^2, whose
+// fp32 error is |oc|/(2r) times smaller, so hit/miss agrees with the f64
+// reference far more often.  Roots are then formed as the reference forms them.
+RT_HD bool sphere_f32(float cx, float cy, float cz, float rad, const RayF &r, float tmin, float tmax, float &t_out) {
+#if RT_ORIGIN_LO
+    const float ocx = (r.ox - cx) + r.lx, ocy = (r.oy - cy) + r.ly, ocz = (r.oz - cz) + r.lz;
+#else
+    const float ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
+#endif
+    const float cd = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    const float dd = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    const float kx = ocy * r.dz - ocz * r.dy, ky = ocz * r.dx - ocx * r.dz, kz = ocx * r.dy - ocy * r.dx;
+    const float disc = dd * (rad * rad) - (kx * kx + ky * ky + kz * kz);
+    if (disc < 0.0f) return false;
+    const float num = -cd;
+    const float sq = __builtin_sqrtf(disc);
+    const float t1 = (num - sq) / dd;
+    const float t2 = (num + sq) / dd;
+    const bool in1 = tmin <= t1 && t1 < tmax, in2 = tmin <= t2 && t2 < tmax;
+    if (in1 && in2) t_out = rt_fmin(t1, t2);
+    else if (in1) t_out = t1;
+    else if (in2) t_out = t2;
+    else return false;
+    return true;
+}
+
+// Triangle::closest_hit (triangle.rs:66-110) in fp32, with a-b and a-c precomputed.
+RT_HD bool triangle_f32(float ax, float ay, float az, float abx, float aby, float abz, float acx, float acy,
+                        float acz, const RayF &r, float tmin, float tmax, float &t_out) {
+    const float aox = RT_REL(ax, r.ox, r.lx), aoy = RT_REL(ay, r.oy, r.ly), aoz = RT_REL(az, r.oz, r.lz);
+    const float det_a = det3_columns_f(abx, aby, abz, acx, acy, acz, r.dx, r.dy, r.dz);
+    if (__builtin_fabsf(det_a) < 2.220446049250313e-16f) return false;
+    const float t = det3_columns_f(abx, aby, abz, acx, acy, acz, aox, aoy, aoz) / det_a;
+    if (t < tmin || t > tmax) return false;
+    const float gamma = det3_columns_f(abx, aby, abz, aox, aoy, aoz, r.dx, r.dy, r.dz) / det_a;
+    if (gamma < 0.0f || gamma > 1.0f) return false;
+    const float beta = det3_columns_f(aox, aoy, aoz, acx, acy, acz, r.dx, r.dy, r.dz) / det_a;
+    if (beta < 0.0f || beta > 1.0f - gamma) return false;
+    t_out = t;
+    return true;
+}
+
+// One sphere / box / triangle payload (RtTPrim::f) against a ray.
+RT_HD bool payload_hit_f32(int32_t type, const rt_f4 &f0, const rt_f4 &f1, const rt_f4 &f2, const RayF &r,
+                           float tmin, float tmax, float &t_out) {
+    if (type == RT_SHAPE_SPHERE) return sphere_f32(f0.x, f0.y, f0.z, f0.w, r, tmin, tmax, t_out);
+    if (type == RT_SHAPE_BOX)  // Cuboid::closest_hit, cuboid.rs:63-73: the box test IS the hit
+        return slab_f32<true>(f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, r, tmin, tmax, t_out);
+    if (type == RT_SHAPE_TRIANGLE)
+        return triangle_f32(f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, r, tmin, tmax, t_out);
+    return false;
+}
+
+// BVH::closest_hit (geometry/bvh.rs:93-125, 140-142) over the scene-level tree and,
+// nested, the trees of meshes and instanced meshes (mesh.rs:91-93, instance.rs:75-94).
+//
+//   ORDERED  visit the nearer child first (else left-then-right like the reference)
+//   ANYHIT   return at the first accepted primitive (shadow rays)
+//   EXACT    true divisions in the node test (else multiply by 1/d)
+//
+// `o`, `d` is the world-space ray in f64; fp32 copies are made here, and again
+// in object space whenever an instance is entered.  The primitive
+// (org_shape, org_tri) is skipped: the caller tests it in f64.
+// Returns false only if the traversal stack would overflow.
+template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
+RT_HD bool traverse(const RtSceneView &S, const D3 &o, const D3 &d, float tmin, HitF &hit, int32_t org_shape,
+                    int32_t org_tri, Stack &stk, int max_sp) {
+    RayF ray;
+    ray_from_f64(o, d, ray);
+    int32_t cur = S.tlas_root;
+    int sp = 0;
+    int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
+    for (;;) {
+        if (cur >= 0) {
+            const rt_f4 *n = S.nodes + (size_t)cur * 4;
+            const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
+            const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
+            float el = 0.0f, er = 0.0f;
+            const bool hl = slab_f32<EXACT>(a.x, a.y, a.z, a.w, b.x, b.y, ray, tmin, hit.t, el);
+            const bool hr =
+                rref != RT_REF_NONE && slab_f32<EXACT>(b.z, b.w, c.x, c.y, c.z, c.w, ray, tmin, hit.t, er);
+            if (hl && hr) {
+                const bool swap = ORDERED && er < el;
+                if (sp >= max_sp) return false;
+                stk.set(sp++, swap ? lref : rref);
+                cur = swap ? rref : lref;
+                continue;
+            }
+            if (hl) { cur = lref; continue; }
+            if (hr) { cur = rref; continue; }
+        } else if (cur == RT_REF_EXIT_BLAS) {
+            ray_from_f64(o, d, ray);  // instance.rs:84 "reset the ray"
+            cur_shape = -1;
+        } else {
+            const uint32_t v = (uint32_t)~cur;
+            const uint32_t cnt = v & 7u, first = v >> 3;
+            if (cur_shape >= 0) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const int32_t gtri = (int32_t)(first + k);
+                    if (cur_shape == org_shape && gtri == org_tri) continue;
+                    const rt_f4 *tp = S.tris + (size_t)gtri * 3;
+                    const rt_f4 f0 = tp[0], f1 = tp[1], f2 = tp[2];
+                    float t;
+                    if (triangle_f32(f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, ray, tmin, hit.t, t)) {
+                        hit.t = t;
+                        hit.shape = cur_shape;
+                        hit.tri = gtri;
+                        if (ANYHIT) return true;
+                    }
+                }
+            } else {
+                bool entered = false;
+                for (uint32_t k = 0; k < cnt && !entered; ++k) {
+                    const rt_f4 *pp = S.tprims + (size_t)(first + k) * 4;
+                    const rt_f4 h = pp[0];
+                    const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
+                                  proto_type = rt_as_int(h.w);
+                    const bool is_inst = type == RT_SHAPE_INSTANCE;
+                    if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
+                        // descend into the mesh; the rest of this leaf waits on the stack
+                        if (sp + 2 > max_sp) return false;
+                        if (k + 1 < cnt) stk.set(sp++, rt_make_leaf_ref(first + k + 1, cnt - k - 1));
+                        stk.set(sp++, RT_REF_EXIT_BLAS);
+                        if (is_inst) {
+                            const double *m = S.shapes[shape_id].inv_transform;
+                            ray_from_f64(transform_point(m, o), transform_vector(m, d), ray);
+                        }
+                        cur_shape = shape_id;
+                        cur = blas_root;
+                        entered = true;
+                    } else if (shape_id != org_shape) {
+                        const rt_f4 f0 = pp[1], f1 = pp[2], f2 = pp[3];
+                        float t;
+                        bool got;
+                        if (is_inst) {
+                            const double *m = S.shapes[shape_id].inv_transform;
+                            RayF lr;
+                            ray_from_f64(transform_point(m, o), transform_vector(m, d), lr);
+                            got = payload_hit_f32(proto_type, f0, f1, f2, lr, tmin, hit.t, t);
+                        } else {
+                            got = payload_hit_f32(type, f0, f1, f2, ray, tmin, hit.t, t);
+                        }
+                        if (got) {
+                            hit.t = t;
+                            hit.shape = shape_id;
+                            hit.tri = -1;
+                            if (ANYHIT) return true;
+                        }
+                    }
+                }
+                if (entered) continue;
+            }
+        }
+        if (sp == 0) break;
+        cur = stk.get(--sp);
+    }
+    return true;
+}
+
+// Traces one ray the way the reference's `scene.bvh.closest_hit(&mut hit)` does,
+// combining the fp32 traversal with the f64 test of the origin primitive.
+// Returns false on stack overflow.
+template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
+RT_HD bool trace_ray(const RtSceneView &S, const D3 &o, const D3 &d, double tmin, double tmax, int32_t org_shape,
+                     int32_t org_tri, Stack &stk, int max_sp, HitF &hit) {
+    hit.t = (float)tmax;
+    hit.shape = -1;
+    hit.tri = -1;
+    // the primitive the ray starts on: f64, the reference's own arithmetic.
+    // A triangle can never be re-hit from a point in its own plane.
+    bool self_hit = false;
+    double self_t = 0.0;
+    if (org_shape >= 0) {
+        const RtShape *sh = &S.shapes[org_shape];
+        const int32_t pt = sh->type == RT_SHAPE_INSTANCE ? S.protos[sh->proto].type : sh->type;
+        if (pt == RT_SHAPE_SPHERE || pt == RT_SHAPE_BOX)
+            self_hit = exact_prim_hit(S, org_shape, -1, o, d, tmin, tmax, false, 0.0, self_t, nullptr);
+    }
+    if (self_hit) {
+        hit.t = (float)self_t;
+        hit.shape = org_shape;
+        hit.tri = -1;
+        if (ANYHIT) return true;
+    }
+    return traverse<Stack, ORDERED, ANYHIT, EXACT>(S, o, d, (float)tmin, hit, org_shape, org_tri, stk, max_sp);
+}
+
+// ---------------------------------------------------------------- camera
+
+// antialias.rs:38-43 + camera/mod.rs:52-56 + perspective.rs:20-28 / orthographic.rs:19-26
+RT_HD void camera_ray(const RtCamera &cam, uint32_t i, uint32_t j, uint32_t p, uint32_t q, uint32_t n, D3 &o, D3 &d) {
+    const double di = ((double)p + 0.5) / (double)n;
+    const double dj = ((double)q + 0.5) / (double)n;
+    const double u = cam.left + (cam.right - cam.left) * ((double)i + di) / (double)cam.pixels_x;
+    const double v = cam.bottom + (cam.top - cam.bottom) * ((double)j + dj) / (double)cam.pixels_y;
+    if (cam.type == RT_CAMERA_PERSPECTIVE) {
+        o = d3(cam.position);
+        d = (d3(cam.u) * u + d3(cam.v) * v) - d3(cam.w) * cam.focal_length;
+    } else {
+        o = d3(cam.position) + D3{u, v, 0.0};
+        d = D3{0.0, 0.0, -1.0};
+    }
+}
+
+// ---------------------------------------------------------------- shading
+
+struct ColorF {
+    float r, g, b;
+};
+
+// One light's contribution (lambertian.rs:29-34, blinn_phong.rs:35-45).
+// `stl` is the un-normalised surface-to-light vector the light returned.
+RT_HD void add_light(const RtShader &sh, const RtLight &light, const D3 &normal, const D3 &stl, const D3 &ray_dir,
+                     ColorF &color) {
+    const D3 stol_normal = normalize(stl);
+    const double cos_incidence = dot(normal, stol_normal);
+    const float k = (float)rt_dmax(cos_incidence, 0.0);
+    color.r += (sh.diffuse[0] * light.intensity[0]) * k;
+    color.g += (sh.diffuse[1] * light.intensity[1]) * k;
+    color.b += (sh.diffuse[2] * light.intensity[2]) * k;
+    if (sh.type == RT_SHADER_BLINN_PHONG) {
+        const D3 half_vector = normalize((-normalize(ray_dir)) + stol_normal);
+        const float s = __builtin_powf((float)rt_dmax(dot(normal, half_vector), 0.0), sh.shininess);
+        color.r += (sh.specular[0] * light.intensity[0]) * s;
+        color.g += (sh.specular[1] * light.intensity[1]) * s;
+        color.b += (sh.specular[2] * light.intensity[2]) * s;
+    }
+}
+
+// perfect_mirror.rs:15-16
+RT_HD D3 mirror_direction(const D3 &ray_dir, const D3 &normal) {
+    const D3 incoming = normalize(ray_dir);
+    return normal * (2.0 * -dot(incoming, normal)) + incoming;
+}

@@ -1,0 +1,260 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE.  Compiles the backend's per-thread stage
+// bodies (rust-raytracer_amd/csrc/rt_pipeline.h, rt_core.h) and its scene
+// flattening (bvh_build.cpp) as ordinary host C++ and runs the stages in plain
+// for-loops, one "thread" at a time.
+//
+// Purpose: exercise the traversal / queue / indexing logic of the device code
+// under a CPU debugger and sanitizers, and measure how often its fp32 decisions
+// differ from the f64 oracle, in a container that has no GPU.  It is not part
+// of librt_hip.so, is never loaded by the package, and is not a fallback: the
+// product path fails when the HIP library or a GPU is missing.
+//
+// fp32 arithmetic here is the host's (SSE, no contraction) and matches the
+// device's IEEE add/mul/div/sqrt; powf may differ in the last bits.
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "../../rust-raytracer_amd/csrc/bvh_build.h"
+#include "../../rust-raytracer_amd/csrc/rt_pipeline.h"
+
+namespace {
+
+struct VecStack {
+    std::vector<int32_t> v;
+    void set(int i, int32_t x) { v[(size_t)i] = x; }
+    int32_t get(int i) const { return v[(size_t)i]; }
+};
+
+struct HostScene {
+    rt::FlatScene flat;
+    std::vector<int32_t> point_lights;
+    RtSceneView view{};
+    bool has_mirror = false, has_lit = false;
+};
+
+std::string make_view(const RtScene &scene, HostScene &hs) {
+    std::string err = rt::flatten_scene(scene, hs.flat);
+    if (!err.empty()) return err;
+    for (uint32_t i = 0; i < scene.n_lights; ++i)
+        if (scene.lights[i].type == RT_LIGHT_POINT) hs.point_lights.push_back((int32_t)i);
+    RtSceneView &V = hs.view;
+    V.nodes = reinterpret_cast<const rt_f4 *>(hs.flat.nodes.data());
+    V.tprims = reinterpret_cast<const rt_f4 *>(hs.flat.tprims.data());
+    V.tris = reinterpret_cast<const rt_f4 *>(hs.flat.tris.data());
+    V.shapes = scene.shapes;
+    V.protos = scene.protos;
+    V.verts64 = hs.flat.verts64.data();
+    V.mesh_tri_base = hs.flat.mesh_tri_base.data();
+    V.shaders = scene.shaders;
+    V.lights = scene.lights;
+    V.point_lights = hs.point_lights.data();
+    V.camera = scene.camera;
+    std::memcpy(V.background, scene.background, sizeof(V.background));
+    V.n_lights = (int32_t)scene.n_lights;
+    V.n_point_lights = (int32_t)hs.point_lights.size();
+    V.tlas_root = hs.flat.tlas_root;
+    V.recursion_depth = scene.recursion_depth;
+    V.disable_shadows = scene.disable_shadows;
+    V.stack_depth = hs.flat.stack_depth;
+    for (uint32_t s = 0; s < scene.n_shapes; ++s) {
+        const int32_t t = scene.shaders[scene.shapes[s].shader].type;
+        hs.has_mirror = hs.has_mirror || t == RT_SHADER_PERFECT_MIRROR;
+        hs.has_lit = hs.has_lit || t == RT_SHADER_LAMBERTIAN || t == RT_SHADER_BLINN_PHONG;
+    }
+    return "";
+}
+
+template <typename T>
+T *grab(std::vector<std::vector<char>> &pool, size_t count) {
+    pool.emplace_back(std::max<size_t>(count, 1) * sizeof(T));
+    return reinterpret_cast<T *>(pool.back().data());
+}
+
+template <bool ORDERED, bool ANYHIT, bool EXACT>
+void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, float *fb, const RtRayIds *ids,
+         RtStats *stats) {
+    const RtSceneView &S = hs.view;
+    const uint32_t n = args.sqrt_rays_per_pixel, spp = n * n;
+    const uint32_t W = scene.image_width, H = scene.image_height;
+    const uint32_t tw = args.tile_w ? args.tile_w : 32, th = args.tile_h ? args.tile_h : 32;
+    const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    const uint32_t parts = std::max<uint32_t>(args.part_count, 1);
+    std::vector<int32_t> tile_list;
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+            const uint32_t k = ty * tiles_x + tx;
+            if (parts <= 1 || (k + ty) % parts == args.part_index) tile_list.push_back((int32_t)k);
+        }
+    const uint32_t n_slots = (uint32_t)tile_list.size();
+    const uint32_t cap = n_slots * tw * th * spp;
+    const uint32_t npl = (uint32_t)S.n_point_lights;
+
+    std::vector<std::vector<char>> pool;
+    RtBuffers Q{};
+    for (int w = 0; w < 2; ++w) {
+        for (int k = 0; k < 3; ++k) {
+            Q.q_o[w][k] = grab<double>(pool, cap);
+            Q.q_d[w][k] = grab<double>(pool, cap);
+        }
+        Q.q_sample[w] = grab<int32_t>(pool, cap);
+        Q.q_org_shape[w] = grab<int32_t>(pool, cap);
+        Q.q_org_tri[w] = grab<int32_t>(pool, cap);
+    }
+    Q.h_t = grab<float>(pool, cap);
+    Q.h_shape = grab<int32_t>(pool, cap);
+    Q.h_tri = grab<int32_t>(pool, cap);
+    for (int k = 0; k < 3; ++k) {
+        Q.s_p[k] = grab<double>(pool, cap);
+        Q.s_n[k] = grab<double>(pool, cap);
+        Q.s_d[k] = grab<double>(pool, cap);
+    }
+    Q.s_sample = grab<int32_t>(pool, cap);
+    Q.s_shape = grab<int32_t>(pool, cap);
+    Q.s_tri = grab<int32_t>(pool, cap);
+    Q.occ_shape = grab<int32_t>(pool, (size_t)cap * std::max(npl, 1u));
+    Q.occ_tri = grab<int32_t>(pool, (size_t)cap * std::max(npl, 1u));
+    Q.color = grab<float>(pool, (size_t)cap * 3);
+    Q.counters = grab<uint32_t>(pool, RT_CNT_SIZE);
+    std::memset(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t));
+    Q.capacity = cap;
+
+    RtBatch B{};
+    B.tile_list = tile_list.data();
+    B.slot0 = 0;
+    B.n_pixels = n_slots * tw * th;
+    B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x;
+    B.width = W; B.height = H;
+    B.n = n;
+    B.compact_fb = 0;  // the simulator always writes the full-image layout
+
+    RtIdOut io{};
+    if (ids) {
+        io.primary_shape = ids->primary_shape; io.primary_tri = ids->primary_tri;
+        io.final_shape = ids->final_shape; io.final_tri = ids->final_tri; io.bounces = ids->bounces;
+        io.shadow_shape = ids->shadow_shape; io.shadow_tri = ids->shadow_tri;
+        const size_t total = (size_t)W * H * spp * npl;
+        for (size_t i = 0; i < total; ++i) {
+            if (io.shadow_shape) io.shadow_shape[i] = -2;
+            if (io.shadow_tri) io.shadow_tri[i] = -2;
+        }
+    }
+    auto alloc_slot = [&](int counter) {
+        uint32_t slot;
+#pragma omp atomic capture
+        slot = Q.counters[counter]++;
+        return slot;
+    };
+
+    // raygen
+    const long n_local = (long)B.n_pixels * spp;
+#pragma omp parallel for schedule(static, 4096)
+    for (long ls = 0; ls < n_local; ++ls) {
+        D3 o, d;
+        if (raygen_classify(S, B, (uint32_t)ls, o, d))
+            queue_write_ray(Q, 0, alloc_slot(RT_CNT_RAYS0), o, d, (int32_t)ls, -1, -1);
+    }
+    const int max_bounce = hs.has_mirror ? S.recursion_depth : 0;
+    for (int bounce = 0; bounce <= max_bounce; ++bounce) {
+        const long count = Q.counters[RT_CNT_RAYS0 + bounce];
+#pragma omp parallel
+        {
+            VecStack stk;
+            stk.v.assign((size_t)std::max(S.stack_depth, 1), 0);
+#pragma omp for schedule(dynamic, 1024)
+            for (long idx = 0; idx < count; ++idx)
+                trace_closest_body<VecStack, ORDERED, EXACT>(S, Q, bounce, (uint32_t)idx, stk);
+#pragma omp for schedule(dynamic, 1024)
+            for (long idx = 0; idx < count; ++idx) {
+                ShadeTmp tmp;
+                const int act = shade_classify(S, Q, B, io, bounce, (uint32_t)idx, tmp);
+                if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, alloc_slot(RT_CNT_RAYS0 + bounce + 1), tmp);
+                if (act == RT_ACT_LIGHTS) shade_commit_lights(Q, alloc_slot(RT_CNT_SHADE), tmp);
+            }
+        }
+    }
+    if (hs.has_lit) {
+        const long entries = Q.counters[RT_CNT_SHADE];
+#pragma omp parallel
+        {
+            VecStack stk;
+            stk.v.assign((size_t)std::max(S.stack_depth, 1), 0);
+            if (!S.disable_shadows)
+                for (uint32_t l = 0; l < npl; ++l) {
+#pragma omp for schedule(dynamic, 1024)
+                    for (long e = 0; e < entries; ++e)
+                        trace_shadow_body<VecStack, ORDERED, ANYHIT, EXACT>(S, Q, l, (uint32_t)e, stk);
+                }
+#pragma omp for schedule(dynamic, 1024)
+            for (long e = 0; e < entries; ++e) accumulate_body(S, Q, B, io, (uint32_t)e);
+        }
+    }
+#pragma omp parallel for schedule(static, 4096)
+    for (long lp = 0; lp < (long)B.n_pixels; ++lp) resolve_body(Q, B, (uint32_t)lp, fb);
+
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->primary_rays = Q.counters[RT_CNT_RAYS0];
+        for (int b = 1; b <= max_bounce; ++b) stats->secondary_rays += Q.counters[RT_CNT_RAYS0 + b];
+        stats->shaded_hits = Q.counters[RT_CNT_SHADE];
+        if (!S.disable_shadows) stats->shadow_rays = (uint64_t)Q.counters[RT_CNT_SHADE] * npl;
+        stats->kernel_launches[0] = Q.counters[RT_CNT_OVERFLOW];  // reused: nonzero = stack overflow
+    }
+}
+
+}  // namespace
+
+extern "C" int hostsim_render(const RtScene *scene, const RtRenderArgs *args, float *fb, const RtRayIds *ids,
+                              RtStats *stats) {
+    HostScene hs;
+    if (!make_view(*scene, hs).empty()) return -1;
+    if (args->mode == RT_MODE_REFERENCE_ORDER) run<false, false, true>(hs, *scene, *args, fb, ids, stats);
+    else run<true, true, false>(hs, *scene, *args, fb, ids, stats);
+    return 0;
+}
+
+extern "C" int hostsim_trace_rays(const RtScene *scene, uint64_t n, const double *o, const double *d,
+                                  const double *tmin, const double *tmax, int32_t mode, float *t_out,
+                                  int32_t *shape_out, int32_t *tri_out) {
+    HostScene hs;
+    if (!make_view(*scene, hs).empty()) return -1;
+    VecStack stk;
+    stk.v.assign((size_t)std::max(hs.view.stack_depth, 1), 0);
+    for (uint64_t r = 0; r < n; ++r) {
+        HitF hit;
+        const D3 ro{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, rd{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]};
+        bool ok;
+        if (mode == RT_MODE_REFERENCE_ORDER)
+            ok = trace_ray<VecStack, false, false, true>(hs.view, ro, rd, tmin[r], tmax[r], -1, -1, stk, hs.view.stack_depth, hit);
+        else
+            ok = trace_ray<VecStack, true, false, false>(hs.view, ro, rd, tmin[r], tmax[r], -1, -1, stk, hs.view.stack_depth, hit);
+        if (!ok) return -2;
+        t_out[r] = hit.t;
+        shape_out[r] = hit.shape;
+        tri_out[r] = tri_file_index(hs.view, hit.tri);
+    }
+    return 0;
+}
+
+// Structure of the flattened trees, for comparison with the oracle's own build:
+// which = -1 scene-level, else mesh index.  Same conventions as oracle_bvh_dump.
+extern "C" int64_t hostsim_bvh_dump(const RtScene *scene, int32_t which, int64_t cap_nodes, int64_t cap_prims,
+                                    int32_t *kinds_out, int32_t *prims_out, double *boxes_out, int64_t *n_prims_out,
+                                    int32_t *stack_depth_out) {
+    rt::FlatScene flat;
+    if (!rt::flatten_scene(*scene, flat).empty()) return -2;
+    const rt::Tree &t = which < 0 ? flat.tlas : flat.blas[(size_t)which];
+    if ((int64_t)t.nodes.size() > cap_nodes || (int64_t)t.order.size() > cap_prims) return -1;
+    for (size_t i = 0; i < t.nodes.size(); ++i) {
+        kinds_out[i] = t.nodes[i].count ? (int32_t)t.nodes[i].count : -1;
+        std::memcpy(boxes_out + i * 6, t.nodes[i].bmin, 3 * sizeof(double));
+        std::memcpy(boxes_out + i * 6 + 3, t.nodes[i].bmax, 3 * sizeof(double));
+    }
+    std::memcpy(prims_out, t.order.data(), t.order.size() * sizeof(int32_t));
+    *n_prims_out = (int64_t)t.order.size();
+    if (stack_depth_out) *stack_depth_out = flat.stack_depth;
+    return (int64_t)t.nodes.size();
+}

@@ -1,0 +1,86 @@
+"""ctypes access to tests/hostsim (the backend's stage bodies compiled for the host)."""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_DIR = os.path.join(ROOT, "tests", "hostsim")
+SIM_LIB = os.path.join(SIM_DIR, "_build", "libhostsim.so")
+
+rt = importlib.import_module("rust-raytracer_amd")
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", SIM_DIR], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SIM_LIB)
+        vp = C.c_void_p
+        L.hostsim_render.argtypes = [vp, C.POINTER(rt.RtRenderArgs), vp, C.POINTER(rt.RtRayIds), C.POINTER(rt.RtStats)]
+        L.hostsim_trace_rays.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
+        L.hostsim_bvh_dump.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int32)]
+        L.hostsim_bvh_dump.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), part=(0, 1)):
+    W, H = scene.image_width, scene.image_height
+    a = rt.RtRenderArgs()
+    a.sqrt_rays_per_pixel = sqrt_rpp
+    a.mode = mode
+    a.tile_w, a.tile_h = tile
+    a.part_index, a.part_count = part
+    fb = np.zeros((H, W, 3), np.float32)
+    ids = rt.RayIds(W * H * sqrt_rpp * sqrt_rpp, scene.n_point_lights) if want_ids else None
+    s = ids.as_struct() if ids is not None else None
+    stats = rt.RtStats()
+    rc = lib().hostsim_render(C.cast(scene.ptr, C.c_void_p), C.byref(a), fb.ctypes.data,
+                              C.byref(s) if s is not None else None, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"hostsim_render failed: {rc}")
+    if stats.kernel_launches[0] != 0:
+        raise RuntimeError("hostsim: traversal stack overflow")
+    return fb, ids, stats
+
+
+def trace_rays(scene, origins, directions, tmin, tmax, mode=rt.RT_MODE_FAST):
+    o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, np.float64).reshape(-1, 3)
+    n = o.shape[0]
+    tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float64), (n,)))
+    tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float64), (n,)))
+    t = np.empty(n, np.float32)
+    shape = np.empty(n, np.int32)
+    tri = np.empty(n, np.int32)
+    rc = lib().hostsim_trace_rays(C.cast(scene.ptr, C.c_void_p), n, o.ctypes.data, d.ctypes.data, tmin.ctypes.data,
+                                  tmax.ctypes.data, mode, t.ctypes.data, shape.ctypes.data, tri.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"hostsim_trace_rays failed: {rc}")
+    return t, shape, tri
+
+
+def bvh_dump(scene, which=-1):
+    cap_nodes, cap_prims = 1 << 20, 1 << 20
+    kinds = np.empty(cap_nodes, np.int32)
+    prims = np.empty(cap_prims, np.int32)
+    boxes = np.empty(cap_nodes * 6, np.float64)
+    n_prims = C.c_int64(0)
+    depth = C.c_int32(0)
+    n = lib().hostsim_bvh_dump(C.cast(scene.ptr, C.c_void_p), which, cap_nodes, cap_prims, kinds.ctypes.data,
+                               prims.ctypes.data, boxes.ctypes.data, C.byref(n_prims), C.byref(depth))
+    if n < 0:
+        raise RuntimeError(f"hostsim_bvh_dump failed: {n}")
+    return kinds[:n].copy(), prims[: n_prims.value].copy(), boxes[: n * 6].reshape(n, 6).copy(), depth.value

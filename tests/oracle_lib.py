@@ -1,0 +1,148 @@
+"""ctypes access to the CPU oracle (oracle/_ref/liboracle.so) for tests, smoke() and
+the benchmark's CPU-baseline leg.  Nothing in the shipped package imports this."""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_ref", "liboracle.so")
+
+rt = importlib.import_module("rust-raytracer_amd")
+
+
+class OracleOutputs(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in rt.ID_FIELDS]
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64 * 3),
+        ("node_tests", C.c_uint64 * 3),
+        ("sphere_tests", C.c_uint64 * 3),
+        ("triangle_tests", C.c_uint64 * 3),
+        ("box_tests", C.c_uint64 * 3),
+        ("instance_visits", C.c_uint64 * 3),
+        ("shaded_hits", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        d = {k: [int(x) for x in getattr(self, k)] for k, _ in self._fields_[:-1]}
+        d["shaded_hits"] = int(self.shaded_hits)
+        return d
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            build()
+        L = C.CDLL(ORACLE_LIB)
+        vp = C.c_void_p
+        L.oracle_render.argtypes = [vp, C.c_uint16, C.c_int, C.c_int, vp, C.POINTER(OracleOutputs), C.POINTER(OracleCounters)]
+        L.oracle_trace_rays.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.oracle_point_light_count.argtypes = [vp]
+        L.oracle_point_light_count.restype = C.c_uint32
+        L.oracle_bbox_hit.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.oracle_primitive_hit.argtypes = [C.c_int, vp, vp, vp, C.c_double, vp, vp, C.c_double, C.c_double,
+                                           C.POINTER(C.c_double), vp]
+        L.oracle_camera_basis.argtypes = [vp, vp, vp, vp]
+        L.oracle_camera_basis.restype = None
+        L.oracle_bvh_dump.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
+        L.oracle_bvh_dump.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _scene_ptr(scene):
+    return C.cast(scene.ptr, C.c_void_p)
+
+
+def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads: int = 0):
+    """Returns (fb [H,W,3] f32, RayIds | None, counters dict)."""
+    W, H = scene.image_width, scene.image_height
+    fb = np.zeros((H, W, 3), np.float32)
+    ids = rt.RayIds(W * H * sqrt_rpp * sqrt_rpp, scene.n_point_lights) if want_ids else None
+    outs = OracleOutputs()
+    if ids is not None:
+        for f in rt.ID_FIELDS:
+            arr = getattr(ids, f)
+            setattr(outs, f, arr.ctypes.data if arr.size else None)
+    cnt = OracleCounters()
+    rc = lib().oracle_render(_scene_ptr(scene), sqrt_rpp, bits, threads, fb.ctypes.data,
+                             C.byref(outs) if ids is not None else None, C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed: {rc}")
+    return fb, ids, cnt.as_dict()
+
+
+def trace_rays(scene, origins, directions, tmin, tmax, bits: int = 64):
+    o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, np.float64).reshape(-1, 3)
+    n = o.shape[0]
+    tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float64), (n,)))
+    tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float64), (n,)))
+    t = np.empty(n, np.float64)
+    shape = np.empty(n, np.int32)
+    tri = np.empty(n, np.int32)
+    normal = np.empty((n, 3), np.float64)
+    rc = lib().oracle_trace_rays(_scene_ptr(scene), n, o.ctypes.data, d.ctypes.data, tmin.ctypes.data,
+                                 tmax.ctypes.data, bits, t.ctypes.data, shape.ctypes.data, tri.ctypes.data,
+                                 normal.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_trace_rays failed: {rc}")
+    return t, shape, tri, normal
+
+
+def _v3(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def bbox_hit(mn, mx, o, d, tmin, tmax):
+    t = C.c_double(0.0)
+    mn, mx, o, d = _v3(mn), _v3(mx), _v3(o), _v3(d)
+    h = lib().oracle_bbox_hit(mn.ctypes.data, mx.ctypes.data, o.ctypes.data, d.ctypes.data, tmin, tmax, C.byref(t))
+    return (t.value if h else None)
+
+
+def primitive_hit(kind, p0, p1, p2, radius, o, d, tmin, tmax):
+    """kind: 0 sphere, 1 box, 2 triangle.  Returns (hit?, t, normal)."""
+    t = C.c_double(0.0)
+    n = np.zeros(3, np.float64)
+    p0, p1, p2, o, d = _v3(p0), _v3(p1), _v3(p2), _v3(o), _v3(d)
+    h = lib().oracle_primitive_hit(kind, p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, radius, o.ctypes.data,
+                                   d.ctypes.data, tmin, tmax, C.byref(t), n.ctypes.data)
+    return bool(h), t.value, n
+
+
+def camera_basis(view):
+    view = _v3(view)
+    u, v, w = np.zeros(3), np.zeros(3), np.zeros(3)
+    lib().oracle_camera_basis(view.ctypes.data, u.ctypes.data, v.ctypes.data, w.ctypes.data)
+    return u, v, w
+
+
+def bvh_dump(scene, which: int = -1):
+    """(kinds, prims, boxes[n,6]) of the oracle's tree, pre-order."""
+    cap_nodes, cap_prims = 1 << 20, 1 << 20
+    kinds = np.empty(cap_nodes, np.int32)
+    prims = np.empty(cap_prims, np.int32)
+    boxes = np.empty(cap_nodes * 6, np.float64)
+    n_prims = C.c_int64(0)
+    n = lib().oracle_bvh_dump(_scene_ptr(scene), which, cap_nodes, cap_prims, kinds.ctypes.data, prims.ctypes.data,
+                              boxes.ctypes.data, C.byref(n_prims))
+    if n < 0:
+        raise RuntimeError("oracle_bvh_dump: capacity too small")
+    return kinds[:n].copy(), prims[: n_prims.value].copy(), boxes[: n * 6].reshape(n, 6).copy()
