@@ -163,6 +163,22 @@ int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const R
                      float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream,
                      RtStats *stats_out);
 
+/* Tile bookkeeping of a partitioned render (no counterpart in the reference, which has
+ * one thread and one image): how many tiles the image has, how many belong to
+ * args->part_index, and the largest count any part owns (= the per-part stride of
+ * a gathered buffer).  A part's compact framebuffer holds its tiles in row-major
+ * tile order, each tile tile_w*tile_h*3 floats, rows bottom-up, padded at the image
+ * edge. */
+int rt_partition_info(uint32_t width, uint32_t height, const RtRenderArgs *args, uint32_t *tiles_total,
+                      uint32_t *tiles_owned, uint32_t *tiles_owned_max);
+
+/* Rebuilds the full framebuffer (framebuffer.rs:21-31 layout) on the device from the
+ * compact framebuffers of all parts laid end to end: `gathered_dev` holds
+ * part_count blocks of tiles_owned_max*tile_w*tile_h*3 floats, block p written by the
+ * render with part_index = p.  Enqueued on `hip_stream` (NULL = backend stream). */
+int rt_untile_device(RtBackend *backend, uint32_t width, uint32_t height, const RtRenderArgs *args,
+                     const float *gathered_dev, float *fb_rgb_dev, void *hip_stream);
+
 /* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
  * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).
  * origins/directions: n x 3 doubles (host).  Outputs (host): t (f32, unchanged

@@ -220,6 +220,9 @@ def lib() -> C.CDLL:
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), C.POINTER(RtStats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp, C.POINTER(RtStats)]
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
+    L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rt_untile_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, vp, vp]
     L.rt_framebuffer_to_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.rt_scene_point_light_count.argtypes = [vp]
     L.rt_scene_point_light_count.restype = C.c_uint32
@@ -426,6 +429,28 @@ class DeviceScene:
             )
         )
         return fb, ids, stats
+
+    def partition_info(self, args: RtRenderArgs):
+        """(tiles_total, tiles_owned, tiles_owned_max) of a partitioned render."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_partition_info(self.width, self.height, C.byref(args), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def render_device(self, args: RtRenderArgs, fb_dev_ptr: int, stream: int = 0, ids: Optional[RtRayIds] = None,
+                      want_stats: bool = False):
+        """rt_render_device: `fb_dev_ptr` is a device address (e.g. a torch tensor's data_ptr())."""
+        stats = RtStats() if want_stats else None
+        _check(
+            lib().rt_render_device(
+                self.backend.handle, self._h, C.byref(args), fb_dev_ptr, C.byref(ids) if ids is not None else None,
+                stream or None, C.byref(stats) if stats is not None else None,
+            )
+        )
+        return stats
+
+    def untile_device(self, args: RtRenderArgs, gathered_dev_ptr: int, fb_dev_ptr: int, stream: int = 0) -> None:
+        _check(lib().rt_untile_device(self.backend.handle, self.width, self.height, C.byref(args), gathered_dev_ptr,
+                                      fb_dev_ptr, stream or None))
 
     def trace_rays(self, origins, directions, tmin, tmax, mode=RT_MODE_FAST):
         """BVH::closest_hit (geometry/bvh.rs:140) on caller-supplied rays."""

@@ -109,6 +109,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_fill_i32(int32_t *p, size_t n, int
     for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK) p[i] = v;
 }
 
+// Scatters gathered tile-major part buffers back into the i + j*width layout.
+// tile_where[k] = owner part * stride_tiles + slot of tile k inside that part.
+__global__ void __launch_bounds__(RT_BLOCK)
+k_untile(const float *gathered, float *fb, const uint32_t *tile_where, uint32_t width, uint32_t height, uint32_t tw,
+         uint32_t th, uint32_t tiles_x) {
+    const uint32_t n_px = width * height;
+    for (uint32_t px = blockIdx.x * RT_BLOCK + threadIdx.x; px < n_px; px += gridDim.x * RT_BLOCK) {
+        const uint32_t i = px % width, j = px / width;
+        const uint32_t tile = (j / th) * tiles_x + i / tw;
+        const size_t src = ((size_t)tile_where[tile] * tw * th + (size_t)(j % th) * tw + i % tw) * 3;
+        fb[(size_t)px * 3 + 0] = gathered[src + 0];
+        fb[(size_t)px * 3 + 1] = gathered[src + 1];
+        fb[(size_t)px * 3 + 2] = gathered[src + 2];
+    }
+}
+
 // BVH::closest_hit on caller-supplied rays (rt_trace_rays).
 template <bool ORDERED, bool EXACT>
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -160,13 +176,17 @@ struct RtBackend {
     int32_t *tile_list = nullptr;
     std::vector<int32_t> tile_list_host;
     uint32_t tile_key[6] = {0, 0, 0, 0, 0, 0};
+    // tile -> position lookup of rt_untile_device
+    uint32_t *tile_where = nullptr;
+    uint32_t untile_key[5] = {0, 0, 0, 0, 0};
     // scratch framebuffer for rt_render
     float *fb = nullptr;
     size_t fb_floats = 0;
 };
 
 struct RtDeviceScene {
-    RtBackend *backend = nullptr;
+    RtBackend *backend = nullptr;  // identity check only; may already be destroyed when the scene is freed
+    int device = 0;
     RtSceneView view{};
     std::vector<void *> allocs;
     uint32_t width = 0, height = 0;
@@ -470,6 +490,7 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
     if (be->stream) (void)hipStreamSynchronize(be->stream);
     free_all(be->buf_allocs);
     if (be->tile_list) (void)hipFree(be->tile_list);
+    if (be->tile_where) (void)hipFree(be->tile_where);
     if (be->fb) (void)hipFree(be->fb);
     if (be->stream) (void)hipStreamDestroy(be->stream);
     delete be;
@@ -494,6 +515,7 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
 
     RtDeviceScene *ds = new RtDeviceScene();
     ds->backend = be;
+    ds->device = be->device;
     auto fail = [&](int rc) {
         free_all(ds->allocs);
         delete ds;
@@ -544,10 +566,8 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
 
 extern "C" void rt_scene_free(RtDeviceScene *ds) {
     if (!ds) return;
-    if (ds->backend) {
-        (void)hipSetDevice(ds->backend->device);
-        if (ds->backend->stream) (void)hipStreamSynchronize(ds->backend->stream);
-    }
+    (void)hipSetDevice(ds->device);
+    (void)hipDeviceSynchronize();
     free_all(ds->allocs);
     delete ds;
 }
@@ -656,6 +676,53 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
         }
     }
     cleanup();
+    return RT_OK;
+}
+
+extern "C" int rt_partition_info(uint32_t width, uint32_t height, const RtRenderArgs *args, uint32_t *tiles_total,
+                                 uint32_t *tiles_owned, uint32_t *tiles_owned_max) {
+    if (!args) return rt::set_error(RT_ERR_INVALID, "null argument");
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
+    std::vector<uint32_t> per_part(parts, 0);
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[parts <= 1 ? 0 : (ty * tiles_x + tx + ty) % parts]++;
+    if (tiles_total) *tiles_total = tiles_x * tiles_y;
+    if (tiles_owned) *tiles_owned = per_part[args->part_index];
+    if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());
+    return RT_OK;
+}
+
+extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, const RtRenderArgs *args,
+                                const float *gathered_dev, float *fb_rgb_dev, void *hip_stream) {
+    if (!be || !args || !gathered_dev || !fb_rgb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+    const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
+    uint32_t stride = 0;
+    int rc = rt_partition_info(width, height, args, nullptr, nullptr, &stride);
+    if (rc) return rc;
+    RT_HIP(hipSetDevice(be->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : be->stream;
+    const uint32_t key[5] = {width, height, tw, th, parts};
+    if (std::memcmp(key, be->untile_key, sizeof(key)) != 0 || !be->tile_where) {
+        std::vector<uint32_t> where((size_t)tiles_x * tiles_y), next(parts, 0);
+        for (uint32_t ty = 0; ty < tiles_y; ++ty)
+            for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+                const uint32_t k = ty * tiles_x + tx, p = parts <= 1 ? 0 : (k + ty) % parts;
+                where[k] = p * stride + next[p]++;
+            }
+        if (be->tile_where) (void)hipFree(be->tile_where);
+        be->tile_where = nullptr;
+        RT_HIP(hipMalloc((void **)&be->tile_where, where.size() * sizeof(uint32_t)));
+        RT_HIP(hipMemcpy(be->tile_where, where.data(), where.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::memcpy(be->untile_key, key, sizeof(key));
+    }
+    hipLaunchKernelGGL(k_untile, dim3(grid_for((uint64_t)width * height)), dim3(RT_BLOCK), 0, stream, gathered_dev,
+                       fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x);
+    RT_HIP(hipGetLastError());
     return RT_OK;
 }
 

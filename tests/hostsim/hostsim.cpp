@@ -216,9 +216,23 @@ extern "C" int hostsim_render(const RtScene *scene, const RtRenderArgs *args, fl
     return 0;
 }
 
+// org_shape / org_tri (may be null): the primitive each ray starts on; org_tri is a
+// triangle index in the mesh's FILE order, as the id outputs report it.
+extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const double *o, const double *d,
+                                       const double *tmin, const double *tmax, int32_t mode,
+                                       const int32_t *org_shape, const int32_t *org_tri, float *t_out,
+                                       int32_t *shape_out, int32_t *tri_out);
+
 extern "C" int hostsim_trace_rays(const RtScene *scene, uint64_t n, const double *o, const double *d,
                                   const double *tmin, const double *tmax, int32_t mode, float *t_out,
                                   int32_t *shape_out, int32_t *tri_out) {
+    return hostsim_trace_rays_from(scene, n, o, d, tmin, tmax, mode, nullptr, nullptr, t_out, shape_out, tri_out);
+}
+
+extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const double *o, const double *d,
+                                       const double *tmin, const double *tmax, int32_t mode,
+                                       const int32_t *org_shape, const int32_t *org_tri, float *t_out,
+                                       int32_t *shape_out, int32_t *tri_out) {
     HostScene hs;
     if (!make_view(*scene, hs).empty()) return -1;
     VecStack stk;
@@ -227,10 +241,19 @@ extern "C" int hostsim_trace_rays(const RtScene *scene, uint64_t n, const double
         HitF hit;
         const D3 ro{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, rd{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]};
         bool ok;
+        int32_t os = org_shape ? org_shape[r] : -1, ot = -1;
+        if (os >= 0 && org_tri && org_tri[r] >= 0) {
+            // file-order index -> leaf-order index of that shape's mesh
+            const RtShape &sh = scene->shapes[os];
+            const int32_t mesh = sh.type == RT_SHAPE_INSTANCE ? scene->protos[sh.proto].mesh : sh.mesh;
+            const uint64_t base = hs.flat.mesh_tri_base[(size_t)mesh];
+            for (uint64_t k = 0; k < scene->meshes[mesh].n_triangles; ++k)
+                if (hs.flat.tris[(size_t)(base + k)].orig == org_tri[r]) ot = (int32_t)(base + k);
+        }
         if (mode == RT_MODE_REFERENCE_ORDER)
-            ok = trace_ray<VecStack, false, false, true>(hs.view, ro, rd, tmin[r], tmax[r], -1, -1, stk, hs.view.stack_depth, hit);
+            ok = trace_ray<VecStack, false, false, true>(hs.view, ro, rd, tmin[r], tmax[r], os, ot, stk, hs.view.stack_depth, hit);
         else
-            ok = trace_ray<VecStack, true, false, false>(hs.view, ro, rd, tmin[r], tmax[r], -1, -1, stk, hs.view.stack_depth, hit);
+            ok = trace_ray<VecStack, true, false, false>(hs.view, ro, rd, tmin[r], tmax[r], os, ot, stk, hs.view.stack_depth, hit);
         if (!ok) return -2;
         t_out[r] = hit.t;
         shape_out[r] = hit.shape;

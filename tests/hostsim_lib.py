@@ -29,6 +29,7 @@ def lib():
         vp = C.c_void_p
         L.hostsim_render.argtypes = [vp, C.POINTER(rt.RtRenderArgs), vp, C.POINTER(rt.RtRayIds), C.POINTER(rt.RtStats)]
         L.hostsim_trace_rays.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
+        L.hostsim_trace_rays_from.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.hostsim_bvh_dump.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int32)]
         L.hostsim_bvh_dump.restype = C.c_int64
@@ -56,7 +57,7 @@ def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), pa
     return fb, ids, stats
 
 
-def trace_rays(scene, origins, directions, tmin, tmax, mode=rt.RT_MODE_FAST):
+def trace_rays(scene, origins, directions, tmin, tmax, mode=rt.RT_MODE_FAST, org_shape=None, org_tri=None):
     o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
     d = np.ascontiguousarray(directions, np.float64).reshape(-1, 3)
     n = o.shape[0]
@@ -65,8 +66,13 @@ def trace_rays(scene, origins, directions, tmin, tmax, mode=rt.RT_MODE_FAST):
     t = np.empty(n, np.float32)
     shape = np.empty(n, np.int32)
     tri = np.empty(n, np.int32)
-    rc = lib().hostsim_trace_rays(C.cast(scene.ptr, C.c_void_p), n, o.ctypes.data, d.ctypes.data, tmin.ctypes.data,
-                                  tmax.ctypes.data, mode, t.ctypes.data, shape.ctypes.data, tri.ctypes.data)
+    os_ = None if org_shape is None else np.ascontiguousarray(org_shape, np.int32)
+    ot_ = None if org_tri is None else np.ascontiguousarray(org_tri, np.int32)
+    rc = lib().hostsim_trace_rays_from(C.cast(scene.ptr, C.c_void_p), n, o.ctypes.data, d.ctypes.data,
+                                       tmin.ctypes.data, tmax.ctypes.data, mode,
+                                       None if os_ is None else os_.ctypes.data,
+                                       None if ot_ is None else ot_.ctypes.data, t.ctypes.data, shape.ctypes.data,
+                                       tri.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"hostsim_trace_rays failed: {rc}")
     return t, shape, tri
