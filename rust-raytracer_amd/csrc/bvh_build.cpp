@@ -268,6 +268,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
 
     // ---- top-level primitives in leaf order
     out.tprims.resize(out.tlas.order.size());
+    out.tprim_xf.assign(out.tlas.order.size() * 12, 0.0f);
     for (size_t k = 0; k < out.tlas.order.size(); ++k) {
         const int32_t id = out.tlas.order[k];
         const RtShape &s = scene.shapes[id];
@@ -280,6 +281,8 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         if (s.type == RT_SHAPE_MESH) {
             p.blas_root = blas_root[(size_t)s.mesh];
         } else if (s.type == RT_SHAPE_INSTANCE) {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 4; ++c) out.tprim_xf[k * 12 + (size_t)r * 4 + c] = (float)s.inv_transform[r * 4 + c];
             const RtShape &proto = scene.protos[s.proto];
             p.proto_type = proto.type;
             if (proto.type == RT_SHAPE_MESH) p.blas_root = blas_root[(size_t)proto.mesh];

@@ -34,6 +34,7 @@ Tree build_tree(std::vector<BuildItem> items);
 struct FlatScene {
     std::vector<RtNode> nodes;
     std::vector<RtTPrim> tprims;
+    std::vector<float> tprim_xf;          // 12 floats per tprim: fp32 rows of an instance's inverse transform
     std::vector<RtTri> tris;
     std::vector<uint64_t> mesh_tri_base;  // first entry of `tris` / `verts64` triangle per mesh
     std::vector<double> verts64;          // 9 doubles per triangle, FILE order, meshes concatenated

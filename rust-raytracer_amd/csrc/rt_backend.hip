@@ -51,53 +51,59 @@ __device__ __forceinline__ uint32_t wave_alloc(bool pred, uint32_t *counter) {
 
 // ------------------------------------------------------------------ kernels
 
-__global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples) {
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n_samples; base += gridDim.x * RT_BLOCK) {
-        const uint32_t ls = base + threadIdx.x;
-        D3 o, d;
-        const bool live = ls < n_samples && raygen_classify(S, B, ls, o, d);
-        const uint32_t slot = wave_alloc(live, &Q.counters[RT_CNT_RAYS0]);
-        if (live) queue_write_ray(Q, 0, slot, o, d, (int32_t)ls, -1, -1);
-    }
-}
-
+// idx = local sample at bounce 0 (count = samples of the batch, passed by the host),
+// queue slot afterwards (count left in device memory by the previous shade stage).
 template <bool ORDERED, bool EXACT>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuffers Q, int bounce) {
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_samples) {
     extern __shared__ int32_t lds[];
     LdsStack stk{lds + threadIdx.x};
-    const uint32_t count = Q.counters[RT_CNT_RAYS0 + bounce];
+    const uint32_t count = bounce == 0 ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
     for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < count; idx += gridDim.x * RT_BLOCK)
-        trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, bounce, idx, stk);
+        trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, B, bounce, idx, stk);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce) {
-    const uint32_t count = Q.counters[RT_CNT_RAYS0 + bounce];
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce, uint32_t n_samples) {
+    const uint32_t count = bounce == 0 ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < count; base += gridDim.x * RT_BLOCK) {
         const uint32_t idx = base + threadIdx.x;
-        ShadeTmp tmp;
+        MirrorTmp tmp;
         const int act = idx < count ? shade_classify(S, Q, B, ids, bounce, idx, tmp) : RT_ACT_NONE;
-        const uint32_t mslot = wave_alloc(act == RT_ACT_MIRROR, &Q.counters[RT_CNT_RAYS0 + bounce + 1]);
-        const uint32_t lslot = wave_alloc(act == RT_ACT_LIGHTS, &Q.counters[RT_CNT_SHADE]);
-        if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, mslot, tmp);
-        if (act == RT_ACT_LIGHTS) shade_commit_lights(Q, lslot, tmp);
+        // mirror rays are sparse: compact them into the next bounce's queue
+        const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, &Q.counters[RT_CNT_RAYS0 + bounce + 1]);
+        if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, slot, tmp);
     }
 }
 
+// Work item w = light_slot * n_samples + sample: consecutive lanes are neighbouring
+// samples aiming at the SAME light, so their shadow rays stay coherent.
 template <bool ORDERED, bool ANYHIT, bool EXACT>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(RtSceneView S, RtBuffers Q) {
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(RtSceneView S, RtBuffers Q, uint32_t n_samples) {
     extern __shared__ int32_t lds[];
     LdsStack stk{lds + threadIdx.x};
-    const uint32_t entries = Q.counters[RT_CNT_SHADE];
-    const uint64_t total = (uint64_t)entries * (uint32_t)S.n_point_lights;
-    // consecutive lanes = neighbouring hit points aiming at the SAME light
+    const uint64_t total = (uint64_t)n_samples * (uint32_t)S.n_point_lights;
     for (uint64_t w = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; w < total; w += (uint64_t)gridDim.x * RT_BLOCK)
-        trace_shadow_body<LdsStack, ORDERED, ANYHIT, EXACT>(S, Q, (uint32_t)(w / entries), (uint32_t)(w % entries), stk);
+        trace_shadow_body<LdsStack, ORDERED, ANYHIT, EXACT>(S, Q, (uint32_t)(w / n_samples), (uint32_t)(w % n_samples), stk);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids) {
-    const uint32_t entries = Q.counters[RT_CNT_SHADE];
-    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < entries; e += gridDim.x * RT_BLOCK)
-        accumulate_body(S, Q, B, ids, e);
+// One block per 256 samples (no grid stride): block b leaves its lit-hit count in block_counts[b].
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples) {
+    const uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool lit = s < n_samples && accumulate_body(S, Q, B, ids, s);
+    const int n = __syncthreads_count(lit ? 1 : 0);
+    if (threadIdx.x == 0) Q.block_counts[blockIdx.x] = (uint32_t)n;
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_sum_block_counts(RtBuffers Q, uint32_t n_blocks) {
+    __shared__ uint32_t part[RT_BLOCK];
+    uint32_t acc = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += RT_BLOCK) acc += Q.block_counts[b];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = RT_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Q.counters[RT_CNT_LIT] = part[0];
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_resolve(RtBuffers Q, RtBatch B, float *fb) {
@@ -134,9 +140,12 @@ k_trace_user(RtSceneView S, uint64_t n, const double *o, const double *d, const 
     LdsStack stk{lds + threadIdx.x};
     for (uint64_t r = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (uint64_t)gridDim.x * RT_BLOCK) {
         HitF hit;
-        const bool ok = trace_ray<LdsStack, ORDERED, false, EXACT>(
-            S, D3{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, D3{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]}, tmin[r], tmax[r],
-            -1, -1, stk, S.stack_depth, hit);
+        hit.t = (float)tmax[r];
+        hit.shape = -1;
+        hit.tri = -1;
+        RayF ray;
+        ray_from_f64(D3{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, D3{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]}, ray);
+        const bool ok = traverse<LdsStack, ORDERED, false, EXACT>(S, ray, (float)tmin[r], hit, -1, -1, stk, S.stack_depth);
         if (!ok) *overflow = 1;
         t_out[r] = hit.t;
         shape_out[r] = hit.shape;
@@ -229,22 +238,24 @@ int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
         if ((rc = alloc_into(be->buf_allocs, &Q.q_sample[w], cap))) return rc;
         if ((rc = alloc_into(be->buf_allocs, &Q.q_org_shape[w], cap))) return rc;
         if ((rc = alloc_into(be->buf_allocs, &Q.q_org_tri[w], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.q_self_t[w], cap))) return rc;
     }
     if ((rc = alloc_into(be->buf_allocs, &Q.h_t, cap))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.h_shape, cap))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.h_tri, cap))) return rc;
     for (int k = 0; k < 3; ++k) {
-        if ((rc = alloc_into(be->buf_allocs, &Q.s_p[k], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.s_n[k], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.s_d[k], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.l_p[k], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.l_n[k], cap))) return rc;
+        if ((rc = alloc_into(be->buf_allocs, &Q.l_d[k], cap))) return rc;
     }
-    if ((rc = alloc_into(be->buf_allocs, &Q.s_sample, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.s_shape, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.s_tri, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.l_shape, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.l_tri, cap))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.occ_shape, cap * npl))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.occ_tri, cap * npl))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.occ_t, cap * npl))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.color, cap * 3))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.counters, (size_t)RT_CNT_SIZE))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.block_counts, cap / RT_BLOCK + 1))) return rc;
     Q.capacity = capacity;
     be->buf_capacity = capacity;
     be->buf_point_lights = n_point_lights;
@@ -390,36 +401,35 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         const uint32_t n_samples = B.n_pixels * spp;
 
         RT_HIP(hipMemsetAsync(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t), stream));
-        if (tm.begin(RT_K_RAYGEN)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_samples)), dim3(RT_BLOCK), 0, stream, S, Q, B, n_samples);
-        tm.end();
-
+        const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         for (int bounce = 0; bounce <= max_bounce; ++bounce) {
-            // queue of bounce b holds at most n_samples rays; later bounces are usually far shorter,
-            // and the grid-stride kernels cost little when their queue is empty
-            const uint32_t g = grid_for(n_samples);
+            // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
+            // the device, so a fixed grid strides over it (and costs little when it is empty).
+            const uint32_t g = bounce == 0 ? full_grid : std::min<uint32_t>(full_grid, RT_MAX_GRID);
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
-                hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, bounce);
+                hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples);
             else
-                hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, bounce);
+                hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples);
             tm.end();
             if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_shade, dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce);
+            hipLaunchKernelGGL(k_shade, dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
             tm.end();
         }
         if (ds->has_lit) {
             const uint64_t shadow_work = (uint64_t)n_samples * ds->n_point_lights;
             if (!S.disable_shadows && ds->n_point_lights > 0) {
+                const uint32_t sg = (uint32_t)((shadow_work + RT_BLOCK - 1) / RT_BLOCK);
                 if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
                 if (ref_order)
-                    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(grid_for(shadow_work)), dim3(RT_BLOCK), lds_bytes, stream, S, Q);
+                    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(sg), dim3(RT_BLOCK), lds_bytes, stream, S, Q, n_samples);
                 else
-                    hipLaunchKernelGGL((k_trace_shadow<true, true, false>), dim3(grid_for(shadow_work)), dim3(RT_BLOCK), lds_bytes, stream, S, Q);
+                    hipLaunchKernelGGL((k_trace_shadow<true, true, false>), dim3(sg), dim3(RT_BLOCK), lds_bytes, stream, S, Q, n_samples);
                 tm.end();
             }
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(n_samples)), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
+            hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io, n_samples);
+            if (stats) hipLaunchKernelGGL(k_sum_block_counts, dim3(1), dim3(RT_BLOCK), 0, stream, Q, full_grid);
             tm.end();
         }
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
@@ -446,12 +456,17 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         (void)hipEventDestroy(ev1);
         tm.collect(stats);
         bool overflow = false;
+        // camera rays = samples of the owned pixels that lie inside the image
+        for (int32_t tile : be->tile_list_host) {
+            const uint32_t x0 = ((uint32_t)tile % tiles_x) * tw, y0 = ((uint32_t)tile / tiles_x) * th;
+            const uint64_t w_in = std::min(tw, W - x0), h_in = std::min(th, H - y0);
+            stats->primary_rays += w_in * h_in * spp;
+        }
         for (size_t at = 0; at < host_counters.size(); at += RT_CNT_SIZE) {
             const uint32_t *c = host_counters.data() + at;
-            stats->primary_rays += c[RT_CNT_RAYS0];
             for (int b = 1; b <= max_bounce && b < 32; ++b) stats->secondary_rays += c[RT_CNT_RAYS0 + b];
-            stats->shaded_hits += c[RT_CNT_SHADE];
-            if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_SHADE] * ds->n_point_lights;
+            stats->shaded_hits += c[RT_CNT_LIT];
+            if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_LIT] * ds->n_point_lights;
             overflow = overflow || c[RT_CNT_OVERFLOW] != 0;
         }
         if (overflow) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
@@ -537,6 +552,7 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
     if ((rc = up(flat.nodes.data(), flat.nodes.size() * sizeof(RtNode), (const void **)&V.nodes))) return fail(rc);
     if ((rc = up(flat.tprims.data(), flat.tprims.size() * sizeof(RtTPrim), (const void **)&V.tprims))) return fail(rc);
     if ((rc = up(flat.tris.data(), flat.tris.size() * sizeof(RtTri), (const void **)&V.tris))) return fail(rc);
+    if ((rc = up(flat.tprim_xf.data(), flat.tprim_xf.size() * sizeof(float), (const void **)&V.tprim_xf))) return fail(rc);
     if ((rc = up(scene->shapes, scene->n_shapes * sizeof(RtShape), (const void **)&V.shapes))) return fail(rc);
     if ((rc = up(scene->protos, scene->n_protos * sizeof(RtShape), (const void **)&V.protos))) return fail(rc);
     if ((rc = up(flat.verts64.data(), flat.verts64.size() * sizeof(double), (const void **)&V.verts64))) return fail(rc);

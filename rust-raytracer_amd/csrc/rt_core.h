@@ -38,10 +38,6 @@ struct alignas(16) rt_f4 {
 };
 #endif
 
-#ifndef RT_ORIGIN_LO
-#define RT_ORIGIN_LO 1  // carry the fp32 rounding residual of ray origins (o = hi + lo)
-#endif
-
 #define RT_VERY_SMALL_NUMBER 1e-6 /* prelude.rs:42 */
 
 // Everything a kernel needs to know about the uploaded scene; passed by value.
@@ -49,6 +45,7 @@ struct RtSceneView {
     const rt_f4 *nodes;   // 4 per RtNode
     const rt_f4 *tprims;  // 4 per RtTPrim
     const rt_f4 *tris;    // 3 per RtTri
+    const rt_f4 *tprim_xf;  // 3 per RtTPrim: rows of the instance's inverse transform (fp32), zeros otherwise
     const RtShape *shapes;
     const RtShape *protos;
     const double *verts64;          // 9 doubles per mesh triangle, file order, meshes concatenated
@@ -261,31 +258,40 @@ RT_HD bool exact_prim_hit(const RtSceneView &S, int32_t shape_id, int32_t gtri, 
 // ---------------------------------------------------------------- fp32 traversal
 
 struct RayF {
-    float ox, oy, oz;  // origin, rounded to fp32
-#if RT_ORIGIN_LO
-    float lx, ly, lz;  // what the rounding dropped
-#endif
-    float dx, dy, dz;
+    float ox, oy, oz;  // origin
+    float dx, dy, dz;  // direction, un-normalised like the reference's rays
     float ix, iy, iz;  // 1 / d (only used by the fast node test)
     bool nx, ny, nz;   // 1/d < 0, the reference's swap condition (bbox.rs:84)
 };
 
-RT_HD void ray_from_f64(const D3 &o, const D3 &d, RayF &r) {
-    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
-#if RT_ORIGIN_LO
-    r.lx = (float)(o.x - (double)r.ox); r.ly = (float)(o.y - (double)r.oy); r.lz = (float)(o.z - (double)r.oz);
-#endif
-    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
+RT_HD void ray_finish(RayF &r) {
     r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
     r.nx = r.ix < 0.0f; r.ny = r.iy < 0.0f; r.nz = r.iz < 0.0f;
 }
 
-// p - origin, using the residual when it is carried
-#if RT_ORIGIN_LO
-#define RT_REL(p, o, l) (((p) - (o)) - (l))
-#else
-#define RT_REL(p, o, l) ((p) - (o))
-#endif
+// The f64 ray of the pipeline, rounded once to fp32 for traversal.
+RT_HD void ray_from_f64(const D3 &o, const D3 &d, RayF &r) {
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
+    ray_finish(r);
+}
+
+// The ray in an instance's object space (instance.rs:77-80): origin as a point,
+// direction as a vector, NOT renormalised, so t means the same in both spaces.
+// fp32 here; the f64 form of the same transform is applied to the winning hit
+// in exact_prim_hit.
+RT_HD void ray_to_instance(const RtSceneView &S, uint32_t tprim_slot, float wox, float woy, float woz, float wdx,
+                           float wdy, float wdz, RayF &out) {
+    const rt_f4 *m = S.tprim_xf + (size_t)tprim_slot * 3;
+    const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
+    out.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+    out.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+    out.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+    out.dx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+    out.dy = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+    out.dz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+    ray_finish(out);
+}
 
 // BBox::hit (bbox.rs:76-125) in closed form.  The reference's three per-axis
 // stages reject exactly when  max(tn) >= min(tf)  or  max(tn) >= tmax  or
@@ -295,13 +301,8 @@ RT_HD void ray_from_f64(const D3 &o, const D3 &d, RayF &r) {
 template <bool EXACT>
 RT_HD bool slab_f32(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const RayF &r, float tmin,
                     float tmax, float &entry) {
-#if RT_ORIGIN_LO
-    const float ax = RT_REL(mnx, r.ox, r.lx), ay = RT_REL(mny, r.oy, r.ly), az = RT_REL(mnz, r.oz, r.lz);
-    const float bx = RT_REL(mxx, r.ox, r.lx), by = RT_REL(mxy, r.oy, r.ly), bz = RT_REL(mxz, r.oz, r.lz);
-#else
     const float ax = mnx - r.ox, ay = mny - r.oy, az = mnz - r.oz;
     const float bx = mxx - r.ox, by = mxy - r.oy, bz = mxz - r.oz;
-#endif
     float t0x, t1x, t0y, t1y, t0z, t1z;
     if (EXACT) {
         t0x = ax / r.dx; t1x = bx / r.dx;
@@ -338,11 +339,7 @@ struct HitF {
 // fp32 error is |oc|/(2r) times smaller, so hit/miss agrees with the f64
 // reference far more often.  Roots are then formed as the reference forms them.
 RT_HD bool sphere_f32(float cx, float cy, float cz, float rad, const RayF &r, float tmin, float tmax, float &t_out) {
-#if RT_ORIGIN_LO
-    const float ocx = (r.ox - cx) + r.lx, ocy = (r.oy - cy) + r.ly, ocz = (r.oz - cz) + r.lz;
-#else
     const float ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
-#endif
     const float cd = ocx * r.dx + ocy * r.dy + ocz * r.dz;
     const float dd = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
     const float kx = ocy * r.dz - ocz * r.dy, ky = ocz * r.dx - ocx * r.dz, kz = ocx * r.dy - ocy * r.dx;
@@ -363,7 +360,7 @@ RT_HD bool sphere_f32(float cx, float cy, float cz, float rad, const RayF &r, fl
 // Triangle::closest_hit (triangle.rs:66-110) in fp32, with a-b and a-c precomputed.
 RT_HD bool triangle_f32(float ax, float ay, float az, float abx, float aby, float abz, float acx, float acy,
                         float acz, const RayF &r, float tmin, float tmax, float &t_out) {
-    const float aox = RT_REL(ax, r.ox, r.lx), aoy = RT_REL(ay, r.oy, r.ly), aoz = RT_REL(az, r.oz, r.lz);
+    const float aox = ax - r.ox, aoy = ay - r.oy, aoz = az - r.oz;
     const float det_a = det3_columns_f(abx, aby, abz, acx, acy, acz, r.dx, r.dy, r.dz);
     if (__builtin_fabsf(det_a) < 2.220446049250313e-16f) return false;
     const float t = det3_columns_f(abx, aby, abz, acx, acy, acz, aox, aoy, aoz) / det_a;
@@ -394,20 +391,23 @@ RT_HD bool payload_hit_f32(int32_t type, const rt_f4 &f0, const rt_f4 &f1, const
 //   ANYHIT   return at the first accepted primitive (shadow rays)
 //   EXACT    true divisions in the node test (else multiply by 1/d)
 //
-// `o`, `d` is the world-space ray in f64; fp32 copies are made here, and again
-// in object space whenever an instance is entered.  The primitive
-// (org_shape, org_tri) is skipped: the caller tests it in f64.
-// Returns false only if the traversal stack would overflow.
+// `ray` is the world-space ray.  `hit` comes in holding the search bound (and, if
+// the caller already found that the ray re-hits the primitive it starts on, that
+// hit).  The primitive (org_shape, org_tri) is skipped here: fp32 cannot decide a
+// re-hit at t ~ 0, so its owner tests it in f64 (self_hit_f64).
+//
+// Loop shape: lanes first walk inner nodes until every lane of the wave holds a
+// leaf (or is done), then all leaves are processed together, so the two bodies
+// are not interleaved lane by lane.  Returns false only on stack overflow.
 template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
-RT_HD bool traverse(const RtSceneView &S, const D3 &o, const D3 &d, float tmin, HitF &hit, int32_t org_shape,
-                    int32_t org_tri, Stack &stk, int max_sp) {
-    RayF ray;
-    ray_from_f64(o, d, ray);
+RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32_t org_shape, int32_t org_tri,
+                    Stack &stk, int max_sp) {
+    const float wox = ray.ox, woy = ray.oy, woz = ray.oz, wdx = ray.dx, wdy = ray.dy, wdz = ray.dz;
     int32_t cur = S.tlas_root;
     int sp = 0;
     int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
             const rt_f4 *n = S.nodes + (size_t)cur * 4;
             const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
             const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
@@ -420,12 +420,19 @@ RT_HD bool traverse(const RtSceneView &S, const D3 &o, const D3 &d, float tmin, 
                 if (sp >= max_sp) return false;
                 stk.set(sp++, swap ? lref : rref);
                 cur = swap ? rref : lref;
-                continue;
+            } else if (hl) {
+                cur = lref;
+            } else if (hr) {
+                cur = rref;
+            } else {
+                cur = sp > 0 ? stk.get(--sp) : RT_REF_NONE;
             }
-            if (hl) { cur = lref; continue; }
-            if (hr) { cur = rref; continue; }
-        } else if (cur == RT_REF_EXIT_BLAS) {
-            ray_from_f64(o, d, ray);  // instance.rs:84 "reset the ray"
+        }
+        if (cur == RT_REF_NONE) break;
+        if (cur == RT_REF_EXIT_BLAS) {
+            // instance.rs:84 "reset the ray"
+            ray.ox = wox; ray.oy = woy; ray.oz = woz; ray.dx = wdx; ray.dy = wdy; ray.dz = wdz;
+            ray_finish(ray);
             cur_shape = -1;
         } else {
             const uint32_t v = (uint32_t)~cur;
@@ -457,10 +464,7 @@ RT_HD bool traverse(const RtSceneView &S, const D3 &o, const D3 &d, float tmin, 
                         if (sp + 2 > max_sp) return false;
                         if (k + 1 < cnt) stk.set(sp++, rt_make_leaf_ref(first + k + 1, cnt - k - 1));
                         stk.set(sp++, RT_REF_EXIT_BLAS);
-                        if (is_inst) {
-                            const double *m = S.shapes[shape_id].inv_transform;
-                            ray_from_f64(transform_point(m, o), transform_vector(m, d), ray);
-                        }
+                        if (is_inst) ray_to_instance(S, first + k, wox, woy, woz, wdx, wdy, wdz, ray);
                         cur_shape = shape_id;
                         cur = blas_root;
                         entered = true;
@@ -469,9 +473,8 @@ RT_HD bool traverse(const RtSceneView &S, const D3 &o, const D3 &d, float tmin, 
                         float t;
                         bool got;
                         if (is_inst) {
-                            const double *m = S.shapes[shape_id].inv_transform;
                             RayF lr;
-                            ray_from_f64(transform_point(m, o), transform_vector(m, d), lr);
+                            ray_to_instance(S, first + k, wox, woy, woz, wdx, wdy, wdz, lr);
                             got = payload_hit_f32(proto_type, f0, f1, f2, lr, tmin, hit.t, t);
                         } else {
                             got = payload_hit_f32(type, f0, f1, f2, ray, tmin, hit.t, t);
@@ -493,32 +496,16 @@ RT_HD bool traverse(const RtSceneView &S, const D3 &o, const D3 &d, float tmin, 
     return true;
 }
 
-// Traces one ray the way the reference's `scene.bvh.closest_hit(&mut hit)` does,
-// combining the fp32 traversal with the f64 test of the origin primitive.
-// Returns false on stack overflow.
-template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
-RT_HD bool trace_ray(const RtSceneView &S, const D3 &o, const D3 &d, double tmin, double tmax, int32_t org_shape,
-                     int32_t org_tri, Stack &stk, int max_sp, HitF &hit) {
-    hit.t = (float)tmax;
-    hit.shape = -1;
-    hit.tri = -1;
-    // the primitive the ray starts on: f64, the reference's own arithmetic.
-    // A triangle can never be re-hit from a point in its own plane.
-    bool self_hit = false;
-    double self_t = 0.0;
-    if (org_shape >= 0) {
-        const RtShape *sh = &S.shapes[org_shape];
-        const int32_t pt = sh->type == RT_SHAPE_INSTANCE ? S.protos[sh->proto].type : sh->type;
-        if (pt == RT_SHAPE_SPHERE || pt == RT_SHAPE_BOX)
-            self_hit = exact_prim_hit(S, org_shape, -1, o, d, tmin, tmax, false, 0.0, self_t, nullptr);
-    }
-    if (self_hit) {
-        hit.t = (float)self_t;
-        hit.shape = org_shape;
-        hit.tri = -1;
-        if (ANYHIT) return true;
-    }
-    return traverse<Stack, ORDERED, ANYHIT, EXACT>(S, o, d, (float)tmin, hit, org_shape, org_tri, stk, max_sp);
+// The f64 test of a secondary ray against the primitive it starts on, with the
+// reference's own arithmetic.  A triangle can never be re-hit from a point in its
+// own plane (t = 0 < t_min), so only spheres and boxes are tested.
+RT_HD bool self_hit_f64(const RtSceneView &S, int32_t org_shape, const D3 &o, const D3 &d, double tmin, double tmax,
+                        double &t_out) {
+    if (org_shape < 0) return false;
+    const RtShape *sh = &S.shapes[org_shape];
+    const int32_t pt = sh->type == RT_SHAPE_INSTANCE ? S.protos[sh->proto].type : sh->type;
+    if (pt != RT_SHAPE_SPHERE && pt != RT_SHAPE_BOX) return false;
+    return exact_prim_hit(S, org_shape, -1, o, d, tmin, tmax, false, 0.0, t_out, nullptr);
 }
 
 // ---------------------------------------------------------------- camera

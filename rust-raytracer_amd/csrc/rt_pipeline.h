@@ -7,59 +7,63 @@
 // of its own and does not attenuate, so a sample is a CHAIN of closest-hit rays
 // that ends in the background or in one diffuse / Blinn-Phong hit; that hit casts
 // one shadow ray per point light.  Here the chain is unrolled into stages that
-// each run over a whole queue of rays:
+// each run over many rays at once:
 //
-//   raygen            sample -> camera ray                       -> ray queue[0]
-//   trace (closest)   ray queue[b] -> hit records
-//   shade             hit records -> colour (background / normal / null shader)
-//                                  | mirror ray                   -> ray queue[b+1]
-//                                  | lit hit                      -> shade queue
-//   (repeat trace + shade while mirror rays remain, at most recursion_depth times)
-//   trace (shadow)    shade queue x point lights -> blocker ids
-//   accumulate        shade queue -> colour, lights summed in scene order
-//   resolve           per pixel: samples summed in p-major order, / n*n  -> framebuffer
+//   trace  (bounce 0)   sample -> camera ray -> closest hit          (hit record per sample)
+//   shade  (bounce 0)   hit -> colour (background / normal / null shader)
+//                           | mirror ray  -> compacted ray queue
+//                           | lit hit     -> that sample's slot of the "lit" table
+//   trace / shade (bounce b >= 1)   the same over the ray queue, while mirror rays remain
+//   trace  (shadow)     lit table x point lights -> blocker ids
+//   accumulate          lit table -> colour, lights summed in scene order
+//   resolve             per pixel: samples summed in p-major order, / n*n  -> framebuffer
 //
-// Every stage body below is written for ONE thread and one queue index; the HIP
-// kernels wrap them in grid-stride loops and do the queue-slot allocation with a
-// wave-wide ballot.  The bodies are plain C++ so a host test build can run them
-// in a for-loop.
+// Camera rays are never stored: trace and shade both rebuild them from the
+// sample index.  A sample ends in at most one lit hit, so the lit table is
+// indexed by sample and needs no compaction; neighbouring lanes stay neighbouring
+// samples.  Only the mirror-ray queue is compacted (wave-wide ballot).
+//
+// Every stage body below is written for ONE thread; the HIP kernels wrap them.
+// The bodies are plain C++ so a host test build can run them in a for-loop.
 #pragma once
 
 #include "rt_core.h"
 
 // Device buffers of one batch of samples (structure of arrays).
 struct RtBuffers {
-    // ray queues, ping-pong by bounce parity
+    // mirror-ray queues, ping-pong by bounce parity: bounce b reads q[b & 1], writes q[(b + 1) & 1]
     double *q_o[2][3];
     double *q_d[2][3];
-    int32_t *q_sample[2];     // local sample index (colour slot)
-    int32_t *q_org_shape[2];  // primitive the ray starts on, -1 for camera rays
+    int32_t *q_sample[2];     // local sample index (colour / lit-table slot)
+    int32_t *q_org_shape[2];  // primitive the ray starts on
     int32_t *q_org_tri[2];
-    // hit records of the queue being processed
+    float *q_self_t[2];       // f64 re-hit of the origin primitive, as fp32 t; +inf = none
+    // hit records: indexed by sample at bounce 0, by queue slot afterwards
     float *h_t;
     int32_t *h_shape;
     int32_t *h_tri;
-    // hits waiting for their lights
-    double *s_p[3];  // hit point
-    double *s_n[3];  // unit normal
-    double *s_d[3];  // direction of the ray that hit (un-normalised)
-    int32_t *s_sample;
-    int32_t *s_shape;
-    int32_t *s_tri;
-    // [point light slot * capacity + shade entry]: blocker, -1 = light visible
+    // lit table, indexed by local sample; l_shape < 0 = this sample has no lit hit
+    double *l_p[3];  // hit point
+    double *l_n[3];  // unit normal
+    double *l_d[3];  // direction of the ray that hit (un-normalised)
+    int32_t *l_shape;
+    int32_t *l_tri;
+    // [point light slot * capacity + sample]: blocker, -1 = light visible
     int32_t *occ_shape;
     int32_t *occ_tri;
+    float *occ_t;     // in: t of the origin primitive's re-hit or 1.0; (reference-order mode) out: blocker t
     // colour of each local sample, 3 floats
     float *color;
     // device counters, see RT_CNT_*
     uint32_t *counters;
-    uint32_t capacity;  // entries every queue can hold
+    uint32_t *block_counts;  // per-block partial sums of lit hits (accumulate stage)
+    uint32_t capacity;       // samples a batch can hold
 };
 
 enum {
-    RT_CNT_RAYS0 = 0,        // [0 .. 31]: rays in queue of bounce b
-    RT_CNT_SHADE = 32,       // shade-queue entries
-    RT_CNT_OVERFLOW = 33,    // traversal-stack overflows (must stay 0)
+    RT_CNT_RAYS0 = 0,      // [1 .. 31]: rays in the queue of bounce b (b >= 1)
+    RT_CNT_LIT = 32,       // lit hits of the batch
+    RT_CNT_OVERFLOW = 33,  // traversal-stack overflows (must stay 0)
     RT_CNT_SIZE = 40
 };
 
@@ -100,23 +104,15 @@ RT_HD int32_t tri_file_index(const RtSceneView &S, int32_t gtri) {
     return gtri < 0 ? -1 : reinterpret_cast<const RtTri *>(S.tris)[gtri].orig;
 }
 
-// ---- raygen: render.rs:64-68
-RT_HD bool raygen_classify(const RtSceneView &S, const RtBatch &B, uint32_t ls, D3 &o, D3 &d) {
+// Camera ray of a local sample (render.rs:64-68); false for the padding pixels of
+// a tile that sticks out of the image.
+RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls, D3 &o, D3 &d) {
     const uint32_t spp = B.n * B.n;
     uint32_t i, j;
     if (!batch_pixel(B, ls / spp, i, j)) return false;
     const uint32_t k = ls % spp;
     camera_ray(S.camera, i, j, k / B.n, k % B.n, B.n, o, d);
     return true;
-}
-
-RT_HD void queue_write_ray(const RtBuffers &Q, int which, uint32_t slot, const D3 &o, const D3 &d, int32_t sample,
-                           int32_t org_shape, int32_t org_tri) {
-    Q.q_o[which][0][slot] = o.x; Q.q_o[which][1][slot] = o.y; Q.q_o[which][2][slot] = o.z;
-    Q.q_d[which][0][slot] = d.x; Q.q_d[which][1][slot] = d.y; Q.q_d[which][2][slot] = d.z;
-    Q.q_sample[which][slot] = sample;
-    Q.q_org_shape[which][slot] = org_shape;
-    Q.q_org_tri[which][slot] = org_tri;
 }
 
 RT_HD void queue_read_ray(const RtBuffers &Q, int which, uint32_t slot, D3 &o, D3 &d) {
@@ -126,29 +122,50 @@ RT_HD void queue_read_ray(const RtBuffers &Q, int which, uint32_t slot, D3 &o, D
 
 // ---- trace (closest): render.rs:70 / perfect_mirror.rs:27.
 // Hit::new gives camera rays t_min = 1.0 (hit_struct.rs:20); mirror rays get
-// VERY_SMALL_NUMBER (perfect_mirror.rs:25).
+// VERY_SMALL_NUMBER (perfect_mirror.rs:25).  idx = local sample (bounce 0) or queue slot.
 template <class Stack, bool ORDERED, bool EXACT>
-RT_HD void trace_closest_body(const RtSceneView &S, const RtBuffers &Q, int bounce, uint32_t idx, Stack &stk) {
-    const int which = bounce & 1;
-    D3 o, d;
-    queue_read_ray(Q, which, idx, o, d);
-    const double tmin = bounce == 0 ? 1.0 : RT_VERY_SMALL_NUMBER;
+RT_HD void trace_closest_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, int bounce, uint32_t idx,
+                              Stack &stk) {
+    RayF ray;
     HitF hit;
-    const bool ok = trace_ray<Stack, ORDERED, false, EXACT>(S, o, d, tmin, (double)__builtin_inff(),
-                                                            Q.q_org_shape[which][idx], Q.q_org_tri[which][idx], stk,
-                                                            S.stack_depth, hit);
-    if (!ok) Q.counters[RT_CNT_OVERFLOW] = 1;
+    hit.t = __builtin_inff();
+    hit.shape = -1;
+    hit.tri = -1;
+    int32_t org_shape = -1, org_tri = -1;
+    float tmin;
+    {
+        D3 o, d;
+        if (bounce == 0) {
+            if (!sample_camera_ray(S, B, idx, o, d)) return;
+            tmin = 1.0f;
+        } else {
+            const int which = bounce & 1;
+            queue_read_ray(Q, which, idx, o, d);
+            org_shape = Q.q_org_shape[which][idx];
+            org_tri = Q.q_org_tri[which][idx];
+            const float self_t = Q.q_self_t[which][idx];
+            if (self_t < hit.t) {
+                hit.t = self_t;
+                hit.shape = org_shape;
+            }
+            tmin = (float)RT_VERY_SMALL_NUMBER;
+        }
+        ray_from_f64(o, d, ray);
+    }
+    if (!traverse<Stack, ORDERED, false, EXACT>(S, ray, tmin, hit, org_shape, org_tri, stk, S.stack_depth))
+        Q.counters[RT_CNT_OVERFLOW] = 1;
     Q.h_t[idx] = hit.t;
     Q.h_shape[idx] = hit.shape;
     Q.h_tri[idx] = hit.tri;
 }
 
 // ---- shade
-enum { RT_ACT_NONE = 0, RT_ACT_MIRROR = 1, RT_ACT_LIGHTS = 2 };
+enum { RT_ACT_NONE = 0, RT_ACT_MIRROR = 1 };
 
-struct ShadeTmp {
-    D3 p, n, d;  // hit point, normal, direction of the incoming ray (MIRROR: of the outgoing ray)
+struct MirrorTmp {
+    D3 p, d;  // origin and direction of the reflected ray
     int32_t sample, shape, tri;
+    float self_t;
 };
 
 RT_HD void write_color(const RtBuffers &Q, int32_t sample, float r, float g, float b) {
@@ -156,11 +173,23 @@ RT_HD void write_color(const RtBuffers &Q, int32_t sample, float r, float g, flo
     c[0] = r; c[1] = g; c[2] = b;
 }
 
-// Decides what happens to queue entry idx of bounce `bounce` (shader/*.rs apply()).
+// Decides what happens to one traced ray (shader/*.rs apply()).  Colours that need
+// no further ray are written here; a lit hit goes into the sample's slot of the lit
+// table together with the origin primitive's own shadow test; a mirror ray is
+// returned for the caller to append to the next queue.
 RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, int bounce,
-                         uint32_t idx, ShadeTmp &tmp) {
-    const int which = bounce & 1;
-    const int32_t sample = Q.q_sample[which][idx];
+                         uint32_t idx, MirrorTmp &tmp) {
+    D3 o, d;
+    int32_t sample;
+    if (bounce == 0) {
+        sample = (int32_t)idx;
+        Q.l_shape[sample] = -1;  // every sample passes here exactly once: this clears the lit table
+        if (!sample_camera_ray(S, B, idx, o, d)) return RT_ACT_NONE;
+    } else {
+        const int which = bounce & 1;
+        sample = Q.q_sample[which][idx];
+        queue_read_ray(Q, which, idx, o, d);
+    }
     const int32_t shape = Q.h_shape[idx], gtri = Q.h_tri[idx];
     const bool want_ids = ids.primary_shape || ids.primary_tri || ids.final_shape || ids.final_tri || ids.bounces;
     const size_t gs = want_ids ? global_sample(B, (uint32_t)sample) : 0;
@@ -176,31 +205,50 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         write_color(Q, sample, S.background[0], S.background[1], S.background[2]);
         return RT_ACT_NONE;
     }
-    D3 o, d;
-    queue_read_ray(Q, which, idx, o, d);
     const double tmin = bounce == 0 ? 1.0 : RT_VERY_SMALL_NUMBER;
     double t = (double)Q.h_t[idx];
     D3 n;
     exact_prim_hit(S, shape, gtri, o, d, tmin, (double)__builtin_inff(), true, t, t, &n);
     const D3 p = o + d * t;  // Hit::hit_point, hit_struct.rs:41-43
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
-    tmp.sample = sample;
-    tmp.shape = shape;
-    tmp.tri = gtri;
-    tmp.p = p;
-    tmp.n = n;
     switch (sh.type) {
     case RT_SHADER_LAMBERTIAN:
-    case RT_SHADER_BLINN_PHONG:
-        tmp.d = d;
-        return RT_ACT_LIGHTS;
-    case RT_SHADER_PERFECT_MIRROR:  // perfect_mirror.rs:9-32
+    case RT_SHADER_BLINN_PHONG: {
+        Q.l_p[0][sample] = p.x; Q.l_p[1][sample] = p.y; Q.l_p[2][sample] = p.z;
+        Q.l_n[0][sample] = n.x; Q.l_n[1][sample] = n.y; Q.l_n[2][sample] = n.z;
+        Q.l_d[0][sample] = d.x; Q.l_d[1][sample] = d.y; Q.l_d[2][sample] = d.z;
+        Q.l_shape[sample] = shape;
+        Q.l_tri[sample] = gtri;
+        if (!S.disable_shadows) {
+            // Hit::to_light (hit_struct.rs:29-39) against the primitive the shadow ray starts on
+            for (int ls = 0; ls < S.n_point_lights; ++ls) {
+                const D3 dir = d3(S.lights[S.point_lights[ls]].position) - p;  // Ray::atob, ray.rs:15-20
+                double st;
+                const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, st);
+                const size_t k = (size_t)ls * Q.capacity + (size_t)sample;
+                Q.occ_t[k] = self ? (float)st : 1.0f;
+                Q.occ_shape[k] = self ? shape : -1;
+                Q.occ_tri[k] = -1;
+            }
+        }
+        return RT_ACT_NONE;
+    }
+    case RT_SHADER_PERFECT_MIRROR: {  // perfect_mirror.rs:9-32
         if (bounce >= S.recursion_depth) {
             write_color(Q, sample, S.background[0], S.background[1], S.background[2]);
             return RT_ACT_NONE;
         }
+        tmp.p = p;
         tmp.d = mirror_direction(d, n);
+        tmp.sample = sample;
+        tmp.shape = shape;
+        tmp.tri = gtri;
+        double st;
+        tmp.self_t = self_hit_f64(S, shape, tmp.p, tmp.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), st)
+                         ? (float)st
+                         : __builtin_inff();
         return RT_ACT_MIRROR;
+    }
     case RT_SHADER_NORMAL:  // normal.rs:10-16
         write_color(Q, sample, (1.0f + (float)n.x) / 2.0f, (1.0f + (float)n.y) / 2.0f, (1.0f + (float)n.z) / 2.0f);
         return RT_ACT_NONE;
@@ -210,46 +258,53 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
     }
 }
 
-RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const ShadeTmp &tmp) {
-    queue_write_ray(Q, (bounce + 1) & 1, slot, tmp.p, tmp.d, tmp.sample, tmp.shape, tmp.tri);
+RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const MirrorTmp &tmp) {
+    const int which = (bounce + 1) & 1;
+    Q.q_o[which][0][slot] = tmp.p.x; Q.q_o[which][1][slot] = tmp.p.y; Q.q_o[which][2][slot] = tmp.p.z;
+    Q.q_d[which][0][slot] = tmp.d.x; Q.q_d[which][1][slot] = tmp.d.y; Q.q_d[which][2][slot] = tmp.d.z;
+    Q.q_sample[which][slot] = tmp.sample;
+    Q.q_org_shape[which][slot] = tmp.shape;
+    Q.q_org_tri[which][slot] = tmp.tri;
+    Q.q_self_t[which][slot] = tmp.self_t;
 }
 
-RT_HD void shade_commit_lights(const RtBuffers &Q, uint32_t slot, const ShadeTmp &tmp) {
-    Q.s_p[0][slot] = tmp.p.x; Q.s_p[1][slot] = tmp.p.y; Q.s_p[2][slot] = tmp.p.z;
-    Q.s_n[0][slot] = tmp.n.x; Q.s_n[1][slot] = tmp.n.y; Q.s_n[2][slot] = tmp.n.z;
-    Q.s_d[0][slot] = tmp.d.x; Q.s_d[1][slot] = tmp.d.y; Q.s_d[2][slot] = tmp.d.z;
-    Q.s_sample[slot] = tmp.sample;
-    Q.s_shape[slot] = tmp.shape;
-    Q.s_tri[slot] = tmp.tri;
-}
-
-// ---- trace (shadow): light/point.rs:30-37.  Work item = (point light slot, shade entry).
+// ---- trace (shadow): light/point.rs:30-37.  Work item = (point light slot, local sample).
 template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
-RT_HD void trace_shadow_body(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t entry,
+RT_HD void trace_shadow_body(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample,
                              Stack &stk) {
-    const RtLight &light = S.lights[S.point_lights[light_slot]];
-    const D3 p = D3{Q.s_p[0][entry], Q.s_p[1][entry], Q.s_p[2][entry]};
-    const D3 dir = d3(light.position) - p;  // Ray::atob, ray.rs:15-20
+    const int32_t org_shape = Q.l_shape[sample];
+    if (org_shape < 0) return;
+    const size_t k = (size_t)light_slot * Q.capacity + sample;
     HitF hit;
-    // Hit::to_light: t = 1.0, t_min = VERY_SMALL_NUMBER (hit_struct.rs:29-39)
-    const bool ok = trace_ray<Stack, ORDERED, ANYHIT, EXACT>(S, p, dir, RT_VERY_SMALL_NUMBER, 1.0, Q.s_shape[entry],
-                                                             Q.s_tri[entry], stk, S.stack_depth, hit);
-    if (!ok) Q.counters[RT_CNT_OVERFLOW] = 1;
-    const size_t k = (size_t)light_slot * Q.capacity + entry;
+    hit.t = Q.occ_t[k];  // 1.0 (Hit::to_light), or the origin primitive's own re-hit
+    hit.shape = Q.occ_shape[k];
+    hit.tri = -1;
+    if (ANYHIT && hit.shape >= 0) return;  // already known to be blocked
+    RayF ray;
+    {
+        const RtLight &light = S.lights[S.point_lights[light_slot]];
+        const D3 p = D3{Q.l_p[0][sample], Q.l_p[1][sample], Q.l_p[2][sample]};
+        ray_from_f64(p, d3(light.position) - p, ray);  // Ray::atob, ray.rs:15-20
+    }
+    if (!traverse<Stack, ORDERED, ANYHIT, EXACT>(S, ray, (float)RT_VERY_SMALL_NUMBER, hit, org_shape, Q.l_tri[sample],
+                                                 stk, S.stack_depth))
+        Q.counters[RT_CNT_OVERFLOW] = 1;
     Q.occ_shape[k] = hit.shape;
     Q.occ_tri[k] = hit.tri;
 }
 
-// ---- accumulate: lambertian.rs:17-36 / blinn_phong.rs:23-47
-RT_HD void accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids,
-                           uint32_t entry) {
-    const D3 p = D3{Q.s_p[0][entry], Q.s_p[1][entry], Q.s_p[2][entry]};
-    const D3 n = D3{Q.s_n[0][entry], Q.s_n[1][entry], Q.s_n[2][entry]};
-    const D3 d = D3{Q.s_d[0][entry], Q.s_d[1][entry], Q.s_d[2][entry]};
-    const int32_t sample = Q.s_sample[entry];
-    const RtShader &sh = S.shaders[S.shapes[Q.s_shape[entry]].shader];
+// ---- accumulate: lambertian.rs:17-36 / blinn_phong.rs:23-47.  Returns true if the
+// sample had a lit hit.
+RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids,
+                           uint32_t sample) {
+    const int32_t shape = Q.l_shape[sample];
+    if (shape < 0) return false;
+    const D3 p = D3{Q.l_p[0][sample], Q.l_p[1][sample], Q.l_p[2][sample]};
+    const D3 n = D3{Q.l_n[0][sample], Q.l_n[1][sample], Q.l_n[2][sample]};
+    const D3 d = D3{Q.l_d[0][sample], Q.l_d[1][sample], Q.l_d[2][sample]};
+    const RtShader &sh = S.shaders[S.shapes[shape].shader];
     const bool want_ids = ids.shadow_shape || ids.shadow_tri;
-    const size_t gs = want_ids ? global_sample(B, (uint32_t)sample) : 0;
+    const size_t gs = want_ids ? global_sample(B, sample) : 0;
     ColorF color = {0.0f, 0.0f, 0.0f};
     int slot = 0;
     for (int li = 0; li < S.n_lights; ++li) {
@@ -260,7 +315,7 @@ RT_HD void accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
         }
         bool visible = true;
         if (!S.disable_shadows) {
-            const size_t k = (size_t)slot * Q.capacity + entry;
+            const size_t k = (size_t)slot * Q.capacity + sample;
             const int32_t blocker = Q.occ_shape[k];
             visible = blocker < 0;
             if (ids.shadow_shape) ids.shadow_shape[gs * (size_t)S.n_point_lights + slot] = blocker;
@@ -270,7 +325,8 @@ RT_HD void accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
         if (visible) add_light(sh, light, n, d3(light.position) - p, d, color);
         ++slot;
     }
-    write_color(Q, sample, color.r, color.g, color.b);
+    write_color(Q, (int32_t)sample, color.r, color.g, color.b);
+    return true;
 }
 
 // ---- resolve: render.rs:63-83, framebuffer.rs:21-31

@@ -45,6 +45,7 @@ std::string make_view(const RtScene &scene, HostScene &hs) {
     V.nodes = reinterpret_cast<const rt_f4 *>(hs.flat.nodes.data());
     V.tprims = reinterpret_cast<const rt_f4 *>(hs.flat.tprims.data());
     V.tris = reinterpret_cast<const rt_f4 *>(hs.flat.tris.data());
+    V.tprim_xf = reinterpret_cast<const rt_f4 *>(hs.flat.tprim_xf.data());
     V.shapes = scene.shapes;
     V.protos = scene.protos;
     V.verts64 = hs.flat.verts64.data();
@@ -103,22 +104,24 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
         Q.q_sample[w] = grab<int32_t>(pool, cap);
         Q.q_org_shape[w] = grab<int32_t>(pool, cap);
         Q.q_org_tri[w] = grab<int32_t>(pool, cap);
+        Q.q_self_t[w] = grab<float>(pool, cap);
     }
     Q.h_t = grab<float>(pool, cap);
     Q.h_shape = grab<int32_t>(pool, cap);
     Q.h_tri = grab<int32_t>(pool, cap);
     for (int k = 0; k < 3; ++k) {
-        Q.s_p[k] = grab<double>(pool, cap);
-        Q.s_n[k] = grab<double>(pool, cap);
-        Q.s_d[k] = grab<double>(pool, cap);
+        Q.l_p[k] = grab<double>(pool, cap);
+        Q.l_n[k] = grab<double>(pool, cap);
+        Q.l_d[k] = grab<double>(pool, cap);
     }
-    Q.s_sample = grab<int32_t>(pool, cap);
-    Q.s_shape = grab<int32_t>(pool, cap);
-    Q.s_tri = grab<int32_t>(pool, cap);
+    Q.l_shape = grab<int32_t>(pool, cap);
+    Q.l_tri = grab<int32_t>(pool, cap);
     Q.occ_shape = grab<int32_t>(pool, (size_t)cap * std::max(npl, 1u));
     Q.occ_tri = grab<int32_t>(pool, (size_t)cap * std::max(npl, 1u));
+    Q.occ_t = grab<float>(pool, (size_t)cap * std::max(npl, 1u));
     Q.color = grab<float>(pool, (size_t)cap * 3);
     Q.counters = grab<uint32_t>(pool, RT_CNT_SIZE);
+    Q.block_counts = grab<uint32_t>(pool, 1);
     std::memset(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t));
     Q.capacity = cap;
 
@@ -149,35 +152,32 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
         return slot;
     };
 
-    // raygen
-    const long n_local = (long)B.n_pixels * spp;
-#pragma omp parallel for schedule(static, 4096)
-    for (long ls = 0; ls < n_local; ++ls) {
-        D3 o, d;
-        if (raygen_classify(S, B, (uint32_t)ls, o, d))
-            queue_write_ray(Q, 0, alloc_slot(RT_CNT_RAYS0), o, d, (int32_t)ls, -1, -1);
-    }
+    const long n_samples = (long)B.n_pixels * spp;
     const int max_bounce = hs.has_mirror ? S.recursion_depth : 0;
     for (int bounce = 0; bounce <= max_bounce; ++bounce) {
-        const long count = Q.counters[RT_CNT_RAYS0 + bounce];
+        const long count = bounce == 0 ? n_samples : (long)Q.counters[RT_CNT_RAYS0 + bounce];
 #pragma omp parallel
         {
             VecStack stk;
             stk.v.assign((size_t)std::max(S.stack_depth, 1), 0);
 #pragma omp for schedule(dynamic, 1024)
             for (long idx = 0; idx < count; ++idx)
-                trace_closest_body<VecStack, ORDERED, EXACT>(S, Q, bounce, (uint32_t)idx, stk);
+                trace_closest_body<VecStack, ORDERED, EXACT>(S, Q, B, bounce, (uint32_t)idx, stk);
 #pragma omp for schedule(dynamic, 1024)
             for (long idx = 0; idx < count; ++idx) {
-                ShadeTmp tmp;
+                MirrorTmp tmp;
                 const int act = shade_classify(S, Q, B, io, bounce, (uint32_t)idx, tmp);
                 if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, alloc_slot(RT_CNT_RAYS0 + bounce + 1), tmp);
-                if (act == RT_ACT_LIGHTS) shade_commit_lights(Q, alloc_slot(RT_CNT_SHADE), tmp);
             }
         }
     }
+    uint64_t primary = 0;
+    for (long ls = 0; ls < n_samples; ++ls) {
+        uint32_t i, j;
+        primary += batch_pixel(B, (uint32_t)(ls / spp), i, j) ? 1 : 0;
+    }
+    long lit = 0;
     if (hs.has_lit) {
-        const long entries = Q.counters[RT_CNT_SHADE];
 #pragma omp parallel
         {
             VecStack stk;
@@ -185,11 +185,11 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
             if (!S.disable_shadows)
                 for (uint32_t l = 0; l < npl; ++l) {
 #pragma omp for schedule(dynamic, 1024)
-                    for (long e = 0; e < entries; ++e)
+                    for (long e = 0; e < n_samples; ++e)
                         trace_shadow_body<VecStack, ORDERED, ANYHIT, EXACT>(S, Q, l, (uint32_t)e, stk);
                 }
-#pragma omp for schedule(dynamic, 1024)
-            for (long e = 0; e < entries; ++e) accumulate_body(S, Q, B, io, (uint32_t)e);
+#pragma omp for schedule(dynamic, 1024) reduction(+ : lit)
+            for (long e = 0; e < n_samples; ++e) lit += accumulate_body(S, Q, B, io, (uint32_t)e) ? 1 : 0;
         }
     }
 #pragma omp parallel for schedule(static, 4096)
@@ -197,10 +197,10 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
 
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->primary_rays = Q.counters[RT_CNT_RAYS0];
+        stats->primary_rays = primary;
         for (int b = 1; b <= max_bounce; ++b) stats->secondary_rays += Q.counters[RT_CNT_RAYS0 + b];
-        stats->shaded_hits = Q.counters[RT_CNT_SHADE];
-        if (!S.disable_shadows) stats->shadow_rays = (uint64_t)Q.counters[RT_CNT_SHADE] * npl;
+        stats->shaded_hits = (uint64_t)lit;
+        if (!S.disable_shadows) stats->shadow_rays = (uint64_t)lit * npl;
         stats->kernel_launches[0] = Q.counters[RT_CNT_OVERFLOW];  // reused: nonzero = stack overflow
     }
 }
@@ -250,10 +250,20 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
             for (uint64_t k = 0; k < scene->meshes[mesh].n_triangles; ++k)
                 if (hs.flat.tris[(size_t)(base + k)].orig == org_tri[r]) ot = (int32_t)(base + k);
         }
+        hit.t = (float)tmax[r];
+        hit.shape = -1;
+        hit.tri = -1;
+        double st;
+        if (self_hit_f64(hs.view, os, ro, rd, tmin[r], tmax[r], st)) {
+            hit.t = (float)st;
+            hit.shape = os;
+        }
+        RayF ray;
+        ray_from_f64(ro, rd, ray);
         if (mode == RT_MODE_REFERENCE_ORDER)
-            ok = trace_ray<VecStack, false, false, true>(hs.view, ro, rd, tmin[r], tmax[r], os, ot, stk, hs.view.stack_depth, hit);
+            ok = traverse<VecStack, false, false, true>(hs.view, ray, (float)tmin[r], hit, os, ot, stk, hs.view.stack_depth);
         else
-            ok = trace_ray<VecStack, true, false, false>(hs.view, ro, rd, tmin[r], tmax[r], os, ot, stk, hs.view.stack_depth, hit);
+            ok = traverse<VecStack, true, false, false>(hs.view, ray, (float)tmin[r], hit, os, ot, stk, hs.view.stack_depth);
         if (!ok) return -2;
         t_out[r] = hit.t;
         shape_out[r] = hit.shape;
