@@ -24,7 +24,9 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_hip.so")
+# RT_HIP_LIB points development builds (kernel variants being timed against each other) at another
+# build of the same library; it never selects a different implementation.
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "csrc", "librt_hip.so")
 
 RT_OK = 0
 RT_ERR_INVALID = -1

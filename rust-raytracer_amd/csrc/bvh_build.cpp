@@ -285,8 +285,15 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
                 for (int c = 0; c < 4; ++c) out.tprim_xf[k * 12 + (size_t)r * 4 + c] = (float)s.inv_transform[r * 4 + c];
             const RtShape &proto = scene.protos[s.proto];
             p.proto_type = proto.type;
-            if (proto.type == RT_SHAPE_MESH) p.blas_root = blas_root[(size_t)proto.mesh];
-            else fill_payload(proto, p.f);
+            if (proto.type == RT_SHAPE_MESH) {
+                p.blas_root = blas_root[(size_t)proto.mesh];
+                // world box of the instance (instance.rs:42), for the fast mode's pre-test
+                const double bmin[3] = {s.bbox_min.x, s.bbox_min.y, s.bbox_min.z};
+                const double bmax[3] = {s.bbox_max.x, s.bbox_max.y, s.bbox_max.z};
+                box_to_f32(bmin, bmax, p.f, p.f + 3);
+            } else {
+                fill_payload(proto, p.f);
+            }
         } else {
             fill_payload(s, p.f);
         }

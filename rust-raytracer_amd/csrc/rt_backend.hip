@@ -29,11 +29,17 @@ namespace {
 
 // ------------------------------------------------------------------ device helpers
 
+// Per-lane traversal stack in LDS, laid out [entry][thread]; six more rows behind the stack
+// rows keep a lane's world-space ray while it is inside an instance.
 struct LdsStack {
     int32_t *base;  // &lds[threadIdx.x]
+    int depth;      // stack rows
     __device__ __forceinline__ void set(int i, int32_t v) { base[i * RT_BLOCK] = v; }
     __device__ __forceinline__ int32_t get(int i) const { return base[i * RT_BLOCK]; }
+    __device__ __forceinline__ void set_aux(int i, float v) { base[(depth + i) * RT_BLOCK] = __float_as_int(v); }
+    __device__ __forceinline__ float get_aux(int i) const { return __int_as_float(base[(depth + i) * RT_BLOCK]); }
 };
+#define RT_LDS_AUX_ROWS 6
 
 // Reserves one slot per lane with `pred` set, using ONE atomic per wave: the
 // 64-bit ballot gives each lane its rank among the wave's appenders.  Must be
@@ -49,15 +55,34 @@ __device__ __forceinline__ uint32_t wave_alloc(bool pred, uint32_t *counter) {
     return base + rank;
 }
 
+// Hardware deals consecutive workgroups round-robin over the 8 XCDs, each with its own
+// 4 MiB L2.  With work items in image order that makes all eight L2s stream the same
+// part of the scene at the same time.  This remap hands XCD x the chunks x, x+8, x+16 ...
+// of `chunk` consecutive logical blocks, so each L2 serves a few tiles' worth of BVH at a
+// time while the interleave keeps the XCDs evenly loaded.  Bijective on [0, n_blocks).
+// (Which physical XCD gets which residue is not defined; only the grouping matters.)
+__device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t b, uint32_t n_blocks, uint32_t chunk) {
+    const uint32_t span = 8u * chunk;
+    const uint32_t full = n_blocks / span * span;  // blocks covered by whole 8-chunk groups
+    if (b >= full) return b;                       // ragged tail: leave in place
+    const uint32_t group = b / span, r = b % span;
+    return group * span + (r % 8u) * chunk + r / 8u;
+}
+
 // ------------------------------------------------------------------ kernels
 
 // idx = local sample at bounce 0 (count = samples of the batch, passed by the host),
 // queue slot afterwards (count left in device memory by the previous shade stage).
 template <bool ORDERED, bool EXACT>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_samples) {
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_samples, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
-    LdsStack stk{lds + threadIdx.x};
-    const uint32_t count = bounce == 0 ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
+    LdsStack stk{lds + threadIdx.x, S.stack_depth};
+    if (bounce == 0) {  // one thread per sample, launched with exactly ceil(n_samples / 256) blocks
+        const uint32_t idx = xcd_chunked_block(blockIdx.x, gridDim.x, xcd_chunk) * RT_BLOCK + threadIdx.x;
+        if (idx < n_samples) trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, B, 0, idx, stk);
+        return;
+    }
+    const uint32_t count = Q.counters[RT_CNT_RAYS0 + bounce];
     for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < count; idx += gridDim.x * RT_BLOCK)
         trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, B, bounce, idx, stk);
 }
@@ -74,36 +99,96 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(RtSceneView S, RtBuffers Q, 
     }
 }
 
-// Work item w = light_slot * n_samples + sample: consecutive lanes are neighbouring
-// samples aiming at the SAME light, so their shadow rays stay coherent.
-template <bool ORDERED, bool ANYHIT, bool EXACT>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(RtSceneView S, RtBuffers Q, uint32_t n_samples) {
+// ---- fast mode.
+//
+// One thread per work item, no persistent loop.  (Handing idle lanes the next ray of a
+// wave-private range was tried: it costs 1.2x .. 1.8x on coherent camera and shadow rays, because
+// the lanes of a wave then sit at different depths of the tree and stop sharing nodes and branches.)
+//
+// KIND 0: closest hit of camera (bounce 0) / mirror rays.  KIND 1: shadow rays of light blockIdx.y.
+template <int KIND>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_samples, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
-    LdsStack stk{lds + threadIdx.x};
-    const uint64_t total = (uint64_t)n_samples * (uint32_t)S.n_point_lights;
-    for (uint64_t w = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; w < total; w += (uint64_t)gridDim.x * RT_BLOCK)
-        trace_shadow_body<LdsStack, ORDERED, ANYHIT, EXACT>(S, Q, (uint32_t)(w / n_samples), (uint32_t)(w % n_samples), stk);
+    LdsStack stk{lds + threadIdx.x, S.stack_depth};
+    uint32_t count;
+    if (KIND == 1) count = Q.counters[RT_CNT_LIT];
+    else count = bounce == 0 ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
+    const uint32_t n_blocks = (count + RT_BLOCK - 1) / RT_BLOCK;  // blocks that have work; the rest leave
+    if (blockIdx.x >= n_blocks) return;
+    const uint32_t idx = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk) * RT_BLOCK + threadIdx.x;
+    if (idx >= count) return;
+    if (KIND == 1) trace_shadow_fast_body<LdsStack>(S, Q, blockIdx.y, Q.lit_list[idx], stk);
+    else trace_closest_fast_body<LdsStack>(S, Q, B, bounce, idx, stk);
 }
 
-// One block per 256 samples (no grid stride): block b leaves its lit-hit count in block_counts[b].
-__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples) {
+// ---- compaction of the lit table into a list of sample indices, in sample order
+// (count per 256-sample block -> exclusive scan of the block counts -> scatter).
+// No global atomics: thousands of waves adding to one counter serialise on it.
+
+__global__ void __launch_bounds__(RT_BLOCK) k_lit_count(RtBuffers Q, uint32_t n_samples) {
     const uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const bool lit = s < n_samples && accumulate_body(S, Q, B, ids, s);
-    const int n = __syncthreads_count(lit ? 1 : 0);
+    const int n = __syncthreads_count(s < n_samples && Q.l_shape[s] >= 0 ? 1 : 0);
     if (threadIdx.x == 0) Q.block_counts[blockIdx.x] = (uint32_t)n;
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_sum_block_counts(RtBuffers Q, uint32_t n_blocks) {
-    __shared__ uint32_t part[RT_BLOCK];
+// One block: block_counts[0..n_blocks) -> exclusive prefix sums in place, total -> counters[RT_CNT_LIT].
+__global__ void __launch_bounds__(1024) k_lit_scan(RtBuffers Q, uint32_t n_blocks) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_blocks);
     uint32_t acc = 0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += RT_BLOCK) acc += Q.block_counts[b];
+    for (uint32_t b = lo; b < hi; ++b) acc += Q.block_counts[b];
     part[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = RT_BLOCK / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) Q.counters[RT_CNT_LIT] = part[0];
+    uint32_t run = part[threadIdx.x] - acc;  // exclusive
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = Q.block_counts[b];
+        Q.block_counts[b] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) Q.counters[RT_CNT_LIT] = part[1023];
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
+    __shared__ uint32_t wave_total[RT_BLOCK / 64];
+    const uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool lit = s < n_samples && Q.l_shape[s] >= 0;
+    const unsigned long long mask = __ballot(lit);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t off = Q.block_counts[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) off += wave_total[w];
+    if (lit) Q.lit_list[off + rank] = s;
+}
+
+// Work item = (point light blockIdx.y, lit entry): consecutive lanes are neighbouring
+// samples aiming at the SAME light, so their shadow rays stay coherent.
+template <bool ORDERED, bool ANYHIT, bool EXACT>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(RtSceneView S, RtBuffers Q, uint32_t xcd_chunk) {
+    extern __shared__ int32_t lds[];
+    LdsStack stk{lds + threadIdx.x, S.stack_depth};
+    const uint32_t n_lit = Q.counters[RT_CNT_LIT];
+    const uint32_t n_blocks = (n_lit + RT_BLOCK - 1) / RT_BLOCK;  // blocks that have work; the rest leave
+    if (blockIdx.x >= n_blocks) return;
+    const uint32_t e = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk) * RT_BLOCK + threadIdx.x;
+    if (e >= n_lit) return;
+    trace_shadow_body<LdsStack, ORDERED, ANYHIT, EXACT>(S, Q, blockIdx.y, Q.lit_list[e], stk);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids) {
+    const uint32_t n_lit = Q.counters[RT_CNT_LIT];
+    const uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (e >= n_lit) return;
+    accumulate_body(S, Q, B, ids, Q.lit_list[e]);
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_resolve(RtBuffers Q, RtBatch B, float *fb) {
@@ -137,15 +222,28 @@ __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_user(RtSceneView S, uint64_t n, const double *o, const double *d, const double *tmin, const double *tmax,
              float *t_out, int32_t *shape_out, int32_t *tri_out, uint32_t *overflow) {
     extern __shared__ int32_t lds[];
-    LdsStack stk{lds + threadIdx.x};
+    LdsStack stk{lds + threadIdx.x, S.stack_depth};
     for (uint64_t r = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (uint64_t)gridDim.x * RT_BLOCK) {
         HitF hit;
         hit.t = (float)tmax[r];
         hit.shape = -1;
         hit.tri = -1;
         RayF ray;
-        ray_from_f64(D3{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, D3{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]}, ray);
-        const bool ok = traverse<LdsStack, ORDERED, false, EXACT>(S, ray, (float)tmin[r], hit, -1, -1, stk, S.stack_depth);
+        ray_from_f64<EXACT>(D3{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, D3{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]}, ray);
+        bool ok;
+        if (EXACT) {
+            ok = traverse<LdsStack, ORDERED, false, EXACT>(S, ray, (float)tmin[r], hit, -1, -1, stk, S.stack_depth);
+        } else {
+            FastTrav st;
+            fast_begin(S, st, stk, D3{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, D3{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]}, hit.t, -1, -1, -1);
+            bool overflow = false;
+            while (fast_step<LdsStack, false>(S, st, stk, (float)tmin[r], S.stack_depth, overflow)) {
+            }
+            ok = !overflow;
+            hit.t = st.t;
+            hit.shape = st.shape;
+            hit.tri = st.tri;
+        }
         if (!ok) *overflow = 1;
         t_out[r] = hit.t;
         shape_out[r] = hit.shape;
@@ -256,6 +354,7 @@ int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
     if ((rc = alloc_into(be->buf_allocs, &Q.color, cap * 3))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.counters, (size_t)RT_CNT_SIZE))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.block_counts, cap / RT_BLOCK + 1))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.lit_list, cap))) return rc;
     Q.capacity = capacity;
     be->buf_capacity = capacity;
     be->buf_point_lights = n_point_lights;
@@ -382,9 +481,11 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         RT_HIP(hipEventCreate(&ev1));
         RT_HIP(hipEventRecord(ev0, stream));
     }
-    const size_t lds_bytes = (size_t)std::max(S.stack_depth, 1) * RT_BLOCK * sizeof(int32_t);
+    const size_t lds_bytes = (size_t)(std::max(S.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
     if (lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
     const bool ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
+    uint32_t xcd_chunk = 128;
+    if (const char *e = std::getenv("RT_XCD_CHUNK")) xcd_chunk = (uint32_t)std::max(1, std::atoi(e));
     const int max_bounce = ds->has_mirror ? S.recursion_depth : 0;
     std::vector<uint32_t> host_counters;
 
@@ -402,34 +503,40 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
 
         RT_HIP(hipMemsetAsync(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t), stream));
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         for (int bounce = 0; bounce <= max_bounce; ++bounce) {
             // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
             // the device, so a fixed grid strides over it (and costs little when it is empty).
             const uint32_t g = bounce == 0 ? full_grid : std::min<uint32_t>(full_grid, RT_MAX_GRID);
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
-                hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples);
+                hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             else
-                hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples);
+                hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
             if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             hipLaunchKernelGGL(k_shade, dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
             tm.end();
         }
         if (ds->has_lit) {
-            const uint64_t shadow_work = (uint64_t)n_samples * ds->n_point_lights;
+            if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            hipLaunchKernelGGL(k_lit_count, dim3(full_grid), dim3(RT_BLOCK), 0, stream, Q, n_samples);
+            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(1024), 0, stream, Q, full_grid);
+            hipLaunchKernelGGL(k_lit_scatter, dim3(full_grid), dim3(RT_BLOCK), 0, stream, Q, n_samples);
+            tm.end();
+            // the number of lit hits is only known on the device: size the grids for the worst
+            // case, surplus blocks return at once
             if (!S.disable_shadows && ds->n_point_lights > 0) {
-                const uint32_t sg = (uint32_t)((shadow_work + RT_BLOCK - 1) / RT_BLOCK);
                 if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                const dim3 sg(full_grid, ds->n_point_lights);
                 if (ref_order)
-                    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(sg), dim3(RT_BLOCK), lds_bytes, stream, S, Q, n_samples);
+                    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
                 else
-                    hipLaunchKernelGGL((k_trace_shadow<true, true, false>), dim3(sg), dim3(RT_BLOCK), lds_bytes, stream, S, Q, n_samples);
+                    hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
                 tm.end();
             }
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io, n_samples);
-            if (stats) hipLaunchKernelGGL(k_sum_block_counts, dim3(1), dim3(RT_BLOCK), 0, stream, Q, full_grid);
+            hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
             tm.end();
         }
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
@@ -769,7 +876,7 @@ extern "C" int rt_trace_rays(RtBackend *be, const RtDeviceScene *ds, uint64_t n,
         hipMemcpy(d_tmax, tmax, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(d_over, 0, sizeof(uint32_t)) != hipSuccess)
         return bail(rt::set_error(RT_ERR_DEVICE, "hipMemcpy to device failed"));
-    const size_t lds_bytes = (size_t)std::max(ds->view.stack_depth, 1) * RT_BLOCK * sizeof(int32_t);
+    const size_t lds_bytes = (size_t)(std::max(ds->view.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
     if (lds_bytes > 64 * 1024) return bail(rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack"));
     if (mode == RT_MODE_REFERENCE_ORDER)
         hipLaunchKernelGGL((k_trace_user<false, true>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);

@@ -40,6 +40,11 @@ struct alignas(16) rt_f4 {
 
 #define RT_VERY_SMALL_NUMBER 1e-6 /* prelude.rs:42 */
 
+// Work counters of the host test build (nodes fetched, primitives tested); nothing on the device.
+#ifndef RT_TALLY
+#define RT_TALLY(what)
+#endif
+
 // Everything a kernel needs to know about the uploaded scene; passed by value.
 struct RtSceneView {
     const rt_f4 *nodes;   // 4 per RtNode
@@ -258,28 +263,55 @@ RT_HD bool exact_prim_hit(const RtSceneView &S, int32_t shape_id, int32_t gtri, 
 // ---------------------------------------------------------------- fp32 traversal
 
 struct RayF {
-    float ox, oy, oz;  // origin
-    float dx, dy, dz;  // direction, un-normalised like the reference's rays
-    float ix, iy, iz;  // 1 / d (only used by the fast node test)
-    bool nx, ny, nz;   // 1/d < 0, the reference's swap condition (bbox.rs:84)
+    float ox, oy, oz;      // origin
+    float dx, dy, dz;      // direction, un-normalised like the reference's rays
+    float ix, iy, iz;      // 1 / d (only used by the fast node test)
+    uint32_t mx, my, mz;   // all ones where 1/d < 0, the reference's swap condition (bbox.rs:84), else 0
 };
 
+RT_HD uint32_t rt_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+RT_HD float rt_float(uint32_t u) { return __builtin_bit_cast(float, u); }
+// m ? a : b for an all-ones / all-zero mask: one v_bfi_b32, and no per-lane boolean for the
+// compiler to keep (and merge at every divergent join) in scalar mask registers.
+RT_HD float rt_select(uint32_t m, float a, float b) { return rt_float((m & rt_bits(a)) | (~m & rt_bits(b))); }
+
+// 1/x for the culling-only node test of the fast mode.
+RT_HD float rt_rcp_approx(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// EXACT: correctly rounded reciprocals (they are not used by the exact node test, which
+// divides, but keep the two modes' RayF identical in meaning).
+template <bool EXACT>
 RT_HD void ray_finish(RayF &r) {
-    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-    r.nx = r.ix < 0.0f; r.ny = r.iy < 0.0f; r.nz = r.iz < 0.0f;
+    if (EXACT) {
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    } else {
+        r.ix = rt_rcp_approx(r.dx); r.iy = rt_rcp_approx(r.dy); r.iz = rt_rcp_approx(r.dz);
+    }
+    // 1/d < 0  <=>  d < 0 or d == -0.0: the sign bit (a NaN direction poisons everything anyway)
+    r.mx = (uint32_t)((int32_t)rt_bits(r.dx) >> 31);
+    r.my = (uint32_t)((int32_t)rt_bits(r.dy) >> 31);
+    r.mz = (uint32_t)((int32_t)rt_bits(r.dz) >> 31);
 }
 
 // The f64 ray of the pipeline, rounded once to fp32 for traversal.
+template <bool EXACT>
 RT_HD void ray_from_f64(const D3 &o, const D3 &d, RayF &r) {
     r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
     r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
-    ray_finish(r);
+    ray_finish<EXACT>(r);
 }
 
 // The ray in an instance's object space (instance.rs:77-80): origin as a point,
 // direction as a vector, NOT renormalised, so t means the same in both spaces.
 // fp32 here; the f64 form of the same transform is applied to the winning hit
 // in exact_prim_hit.
+template <bool EXACT>
 RT_HD void ray_to_instance(const RtSceneView &S, uint32_t tprim_slot, float wox, float woy, float woz, float wdx,
                            float wdy, float wdz, RayF &out) {
     const rt_f4 *m = S.tprim_xf + (size_t)tprim_slot * 3;
@@ -290,7 +322,7 @@ RT_HD void ray_to_instance(const RtSceneView &S, uint32_t tprim_slot, float wox,
     out.dx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
     out.dy = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
     out.dz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-    ray_finish(out);
+    ray_finish<EXACT>(out);
 }
 
 // BBox::hit (bbox.rs:76-125) in closed form.  The reference's three per-axis
@@ -313,9 +345,9 @@ RT_HD bool slab_f32(float mnx, float mny, float mnz, float mxx, float mxy, float
         t0y = ay * r.iy; t1y = by * r.iy;
         t0z = az * r.iz; t1z = bz * r.iz;
     }
-    const float tnx = r.nx ? t1x : t0x, tfx = r.nx ? t0x : t1x;
-    const float tny = r.ny ? t1y : t0y, tfy = r.ny ? t0y : t1y;
-    const float tnz = r.nz ? t1z : t0z, tfz = r.nz ? t0z : t1z;
+    const float tnx = rt_select(r.mx, t1x, t0x), tfx = rt_select(r.mx, t0x, t1x);
+    const float tny = rt_select(r.my, t1y, t0y), tfy = rt_select(r.my, t0y, t1y);
+    const float tnz = rt_select(r.mz, t1z, t0z), tfz = rt_select(r.mz, t0z, t1z);
     // per-axis emptiness (tn_k >= tf_k) is part of max(tn) >= min(tf)
     const float e = rt_fmax(rt_fmax(tnx, tny), tnz);
     const float x = rt_fmin(rt_fmin(tfx, tfy), tfz);
@@ -402,12 +434,16 @@ RT_HD bool payload_hit_f32(int32_t type, const rt_f4 &f0, const rt_f4 &f1, const
 template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
 RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32_t org_shape, int32_t org_tri,
                     Stack &stk, int max_sp) {
+#if defined(RT_ABLATE) && RT_ABLATE == 1
+    return true;
+#endif
     const float wox = ray.ox, woy = ray.oy, woz = ray.oz, wdx = ray.dx, wdy = ray.dy, wdz = ray.dz;
     int32_t cur = S.tlas_root;
     int sp = 0;
     int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
     for (;;) {
         while (cur >= 0) {
+            RT_TALLY(node);
             const rt_f4 *n = S.nodes + (size_t)cur * 4;
             const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
             const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
@@ -432,7 +468,7 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
         if (cur == RT_REF_EXIT_BLAS) {
             // instance.rs:84 "reset the ray"
             ray.ox = wox; ray.oy = woy; ray.oz = woz; ray.dx = wdx; ray.dy = wdy; ray.dz = wdz;
-            ray_finish(ray);
+            ray_finish<EXACT>(ray);
             cur_shape = -1;
         } else {
             const uint32_t v = (uint32_t)~cur;
@@ -441,6 +477,10 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const int32_t gtri = (int32_t)(first + k);
                     if (cur_shape == org_shape && gtri == org_tri) continue;
+#if defined(RT_ABLATE) && RT_ABLATE == 2
+                    continue;
+#endif
+                    RT_TALLY(tri);
                     const rt_f4 *tp = S.tris + (size_t)gtri * 3;
                     const rt_f4 f0 = tp[0], f1 = tp[1], f2 = tp[2];
                     float t;
@@ -459,27 +499,29 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
                     const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
                                   proto_type = rt_as_int(h.w);
                     const bool is_inst = type == RT_SHAPE_INSTANCE;
+                    RT_TALLY(tprim);
                     if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
+                        if (!EXACT && is_inst) {
+                            // fast mode: skip the transform when the ray misses the instance's world box
+                            // (the reference has no such test; it cannot change a hit, only save work)
+                            const rt_f4 f0 = pp[1], f1 = pp[2];
+                            float e;
+                            if (!slab_f32<false>(f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, ray, tmin, hit.t, e)) continue;
+                        }
                         // descend into the mesh; the rest of this leaf waits on the stack
                         if (sp + 2 > max_sp) return false;
                         if (k + 1 < cnt) stk.set(sp++, rt_make_leaf_ref(first + k + 1, cnt - k - 1));
                         stk.set(sp++, RT_REF_EXIT_BLAS);
-                        if (is_inst) ray_to_instance(S, first + k, wox, woy, woz, wdx, wdy, wdz, ray);
+                        if (is_inst) ray_to_instance<EXACT>(S, first + k, wox, woy, woz, wdx, wdy, wdz, ray);
                         cur_shape = shape_id;
                         cur = blas_root;
                         entered = true;
                     } else if (shape_id != org_shape) {
                         const rt_f4 f0 = pp[1], f1 = pp[2], f2 = pp[3];
+                        RayF lr = ray;
+                        if (is_inst) ray_to_instance<EXACT>(S, first + k, wox, woy, woz, wdx, wdy, wdz, lr);
                         float t;
-                        bool got;
-                        if (is_inst) {
-                            RayF lr;
-                            ray_to_instance(S, first + k, wox, woy, woz, wdx, wdy, wdz, lr);
-                            got = payload_hit_f32(proto_type, f0, f1, f2, lr, tmin, hit.t, t);
-                        } else {
-                            got = payload_hit_f32(type, f0, f1, f2, ray, tmin, hit.t, t);
-                        }
-                        if (got) {
+                        if (payload_hit_f32(is_inst ? proto_type : type, f0, f1, f2, lr, tmin, hit.t, t)) {
                             hit.t = t;
                             hit.shape = shape_id;
                             hit.tri = -1;
@@ -494,6 +536,193 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
         cur = stk.get(--sp);
     }
     return true;
+}
+
+// ---------------------------------------------------------------- fast-mode traversal
+//
+// Same tree, same primitives, same closest hit as traverse<> above (ties aside), but the
+// arithmetic is arranged for the GPU rather than to mirror the reference line by line:
+//   * node test: (p - o) * (1/d) with min/max per axis instead of a sign-selected swap.
+//     1/d is clamped to +-FLT_MAX so that 0 * (1/0) is 0, not NaN: a ray lying in a box
+//     face's plane then treats that axis as unconstrained on the entry side like the
+//     reference does.  The test only culls; primitives decide hits.
+//   * triangle test: the four determinants of triangle.rs:76-105 share their two cross
+//     products and one reciprocal of det A replaces the three divisions.
+// It is a resumable state machine (begin / step) so that a kernel can hand a finished
+// lane its next ray while the other lanes of the wave keep traversing.
+
+struct FastTrav {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;  // current-space ray and clamped 1/d
+    float t;                                   // search bound / closest hit so far
+    int32_t shape, tri;                        // closest hit so far
+    int32_t cur, sp, cur_shape;                // traversal position
+    int32_t org_shape, org_tri;                // primitive the ray starts on (skipped)
+};
+
+RT_HD float rt_inv_clamped(float d) {
+    const float big = 3.4028234e38f;
+    const float r = rt_rcp_approx(d);
+    return rt_fmin(rt_fmax(r, -big), big);
+}
+
+RT_HD void fast_set_ray(FastTrav &s, float ox, float oy, float oz, float dx, float dy, float dz) {
+    s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
+    s.ix = rt_inv_clamped(dx); s.iy = rt_inv_clamped(dy); s.iz = rt_inv_clamped(dz);
+}
+
+// Aux slots 0..5 of the stack object hold the world-space ray while a lane is inside an instance.
+template <class Stack>
+RT_HD void fast_begin(const RtSceneView &S, FastTrav &s, Stack &stk, const D3 &o, const D3 &d, float t0,
+                      int32_t shape0, int32_t org_shape, int32_t org_tri) {
+    fast_set_ray(s, (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
+    stk.set_aux(0, s.ox); stk.set_aux(1, s.oy); stk.set_aux(2, s.oz);
+    stk.set_aux(3, s.dx); stk.set_aux(4, s.dy); stk.set_aux(5, s.dz);
+    s.t = t0;
+    s.shape = shape0;
+    s.tri = -1;
+    s.cur = S.tlas_root;
+    s.sp = 0;
+    s.cur_shape = -1;
+    s.org_shape = org_shape;
+    s.org_tri = org_tri;
+}
+
+// Entry distance of the ray into a box within (tmin, s.t), or a miss.
+RT_HD bool fast_box(const FastTrav &s, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tmin,
+                    float &entry) {
+    const float t0x = (mnx - s.ox) * s.ix, t1x = (mxx - s.ox) * s.ix;
+    const float t0y = (mny - s.oy) * s.iy, t1y = (mxy - s.oy) * s.iy;
+    const float t0z = (mnz - s.oz) * s.iz, t1z = (mxz - s.oz) * s.iz;
+    const float e = rt_fmax(rt_fmax(rt_fmax(rt_fmin(t0x, t1x), rt_fmin(t0y, t1y)), rt_fmin(t0z, t1z)), tmin);
+    const float x = rt_fmin(rt_fmin(rt_fmin(rt_fmax(t0x, t1x), rt_fmax(t0y, t1y)), rt_fmax(t0z, t1z)), s.t);
+    entry = e;
+    return e < x;
+}
+
+RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &f0, const rt_f4 &f1, const rt_f4 &f2, float tmin, float &t_out) {
+    const float ax = f0.x, ay = f0.y, az = f0.z, abx = f0.w, aby = f1.x, abz = f1.y, acx = f1.z, acy = f1.w, acz = f2.x;
+    // c = ac x d ; det A = det[ab ac d] = ab . c
+    const float cx = acy * s.dz - acz * s.dy, cy = acz * s.dx - acx * s.dz, cz = acx * s.dy - acy * s.dx;
+    const float det_a = abx * cx + aby * cy + abz * cz;
+    if (__builtin_fabsf(det_a) < 2.220446049250313e-16f) return false;
+    const float inv_det = rt_rcp_approx(det_a);
+    const float aox = ax - s.ox, aoy = ay - s.oy, aoz = az - s.oz;
+    // q = ab x ao ; det[ab ac ao] = -(ac . q) ; det[ab ao d] = d . q ; det[ao ac d] = ao . c
+    const float qx = aby * aoz - abz * aoy, qy = abz * aox - abx * aoz, qz = abx * aoy - aby * aox;
+    const float t = -(acx * qx + acy * qy + acz * qz) * inv_det;
+    if (!(t >= tmin && t <= s.t)) return false;
+    const float gamma = (s.dx * qx + s.dy * qy + s.dz * qz) * inv_det;
+    if (!(gamma >= 0.0f && gamma <= 1.0f)) return false;
+    const float beta = (aox * cx + aoy * cy + aoz * cz) * inv_det;
+    if (!(beta >= 0.0f && beta <= 1.0f - gamma)) return false;
+    t_out = t;
+    return true;
+}
+
+// One outer iteration: walk inner nodes until a leaf (or the end), then process that leaf.
+// Returns false when the ray is finished (stack empty, any-hit satisfied, or overflow flagged).
+template <class Stack, bool ANYHIT>
+RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, int max_sp, bool &overflow) {
+    const char *node_base = reinterpret_cast<const char *>(S.nodes);
+    int32_t cur = s.cur;
+    int sp = s.sp;
+    while (cur >= 0) {
+        RT_TALLY(node);
+        const rt_f4 *n = reinterpret_cast<const rt_f4 *>(node_base + ((uint32_t)cur << 6));
+        const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
+        const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
+        float el, er;
+        const bool hl = fast_box(s, a.x, a.y, a.z, a.w, b.x, b.y, tmin, el);
+        const bool hr = fast_box(s, b.z, b.w, c.x, c.y, c.z, c.w, tmin, er) && rref != RT_REF_NONE;
+        if (hl && hr) {
+            const bool swap = er < el;
+            if (sp >= max_sp) { overflow = true; return false; }
+            stk.set(sp++, swap ? lref : rref);
+            cur = swap ? rref : lref;
+        } else if (hl) {
+            cur = lref;
+        } else if (hr) {
+            cur = rref;
+        } else {
+            cur = sp > 0 ? stk.get(--sp) : RT_REF_NONE;
+        }
+    }
+    if (cur == RT_REF_NONE) { s.cur = cur; s.sp = sp; return false; }
+    bool entered = false;
+    if (cur == RT_REF_EXIT_BLAS) {
+        fast_set_ray(s, stk.get_aux(0), stk.get_aux(1), stk.get_aux(2), stk.get_aux(3), stk.get_aux(4), stk.get_aux(5));
+        s.cur_shape = -1;
+    } else {
+        const uint32_t v = (uint32_t)~cur;
+        const uint32_t cnt = v & 7u, first = v >> 3;
+        if (s.cur_shape >= 0) {
+            const char *tri_base = reinterpret_cast<const char *>(S.tris);
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const int32_t gtri = (int32_t)(first + k);
+                if (s.cur_shape == s.org_shape && gtri == s.org_tri) continue;
+                RT_TALLY(tri);
+                const rt_f4 *tp = reinterpret_cast<const rt_f4 *>(tri_base + (uint32_t)gtri * 48u);
+                float t;
+                if (fast_triangle(s, tp[0], tp[1], tp[2], tmin, t)) {
+                    s.t = t;
+                    s.shape = s.cur_shape;
+                    s.tri = gtri;
+                    if (ANYHIT) { s.cur = RT_REF_NONE; return false; }
+                }
+            }
+        } else {
+            for (uint32_t k = 0; k < cnt && !entered; ++k) {
+                const rt_f4 *pp = S.tprims + (size_t)(first + k) * 4;
+                const rt_f4 h = pp[0];
+                const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
+                              proto_type = rt_as_int(h.w);
+                const bool is_inst = type == RT_SHAPE_INSTANCE;
+                RT_TALLY(tprim);
+                if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
+                    if (is_inst) {
+                        // skip the transform when the ray misses the instance's world box (the reference
+                        // has no such test; it cannot change a hit, only save work)
+                        const rt_f4 f0 = pp[1], f1 = pp[2];
+                        float e;
+                        if (!fast_box(s, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e)) continue;
+                    }
+                    if (sp + 2 > max_sp) { overflow = true; return false; }
+                    if (k + 1 < cnt) stk.set(sp++, rt_make_leaf_ref(first + k + 1, cnt - k - 1));
+                    stk.set(sp++, RT_REF_EXIT_BLAS);
+                    if (is_inst) {
+                        const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
+                        const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
+                        const float wox = s.ox, woy = s.oy, woz = s.oz, wdx = s.dx, wdy = s.dy, wdz = s.dz;
+                        fast_set_ray(s, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
+                                     ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
+                                     ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
+                                     (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
+                                     (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+                    }
+                    s.cur_shape = shape_id;
+                    cur = blas_root;
+                    entered = true;
+                } else if (shape_id != s.org_shape) {
+                    // sphere / box / triangle at scene level, possibly instanced: the reference-shaped tests
+                    RayF lr;
+                    lr.ox = s.ox; lr.oy = s.oy; lr.oz = s.oz; lr.dx = s.dx; lr.dy = s.dy; lr.dz = s.dz;
+                    if (is_inst) ray_to_instance<false>(S, first + k, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, lr);
+                    else ray_finish<false>(lr);
+                    float t;
+                    if (payload_hit_f32(is_inst ? proto_type : type, pp[1], pp[2], pp[3], lr, tmin, s.t, t)) {
+                        s.t = t;
+                        s.shape = shape_id;
+                        s.tri = -1;
+                        if (ANYHIT) { s.cur = RT_REF_NONE; return false; }
+                    }
+                }
+            }
+        }
+    }
+    if (!entered) cur = sp > 0 ? stk.get(--sp) : RT_REF_NONE;
+    s.cur = cur;
+    s.sp = sp;
+    return cur != RT_REF_NONE;
 }
 
 // The f64 test of a secondary ray against the primitive it starts on, with the

@@ -56,7 +56,8 @@ struct RtBuffers {
     float *color;
     // device counters, see RT_CNT_*
     uint32_t *counters;
-    uint32_t *block_counts;  // per-block partial sums of lit hits (accumulate stage)
+    uint32_t *block_counts;  // per-256-sample-block lit counts, then their exclusive prefix sums
+    uint32_t *lit_list;      // samples that have a lit hit, ascending
     uint32_t capacity;       // samples a batch can hold
 };
 
@@ -123,40 +124,81 @@ RT_HD void queue_read_ray(const RtBuffers &Q, int which, uint32_t slot, D3 &o, D
 // ---- trace (closest): render.rs:70 / perfect_mirror.rs:27.
 // Hit::new gives camera rays t_min = 1.0 (hit_struct.rs:20); mirror rays get
 // VERY_SMALL_NUMBER (perfect_mirror.rs:25).  idx = local sample (bounce 0) or queue slot.
+
+struct RaySetup {
+    D3 o, d;            // the f64 ray
+    float t0;           // initial search bound (or the origin primitive's own re-hit)
+    int32_t shape0;     // -1, or the origin primitive when t0 is its re-hit
+    int32_t org_shape, org_tri;
+};
+
+RT_HD float closest_tmin(int bounce) { return bounce == 0 ? 1.0f : (float)RT_VERY_SMALL_NUMBER; }
+
+// False for the padding samples of a tile that sticks out of the image.
+RT_HD bool closest_setup(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, int bounce, uint32_t idx,
+                         RaySetup &r) {
+    r.t0 = __builtin_inff();
+    r.shape0 = -1;
+    r.org_shape = -1;
+    r.org_tri = -1;
+    if (bounce == 0) return sample_camera_ray(S, B, idx, r.o, r.d);
+    const int which = bounce & 1;
+    queue_read_ray(Q, which, idx, r.o, r.d);
+    r.org_shape = Q.q_org_shape[which][idx];
+    r.org_tri = Q.q_org_tri[which][idx];
+    const float self_t = Q.q_self_t[which][idx];
+    if (self_t < r.t0) {
+        r.t0 = self_t;
+        r.shape0 = r.org_shape;
+    }
+    return true;
+}
+
+RT_HD void closest_store(const RtBuffers &Q, uint32_t idx, float t, int32_t shape, int32_t tri) {
+    Q.h_t[idx] = t;
+    Q.h_shape[idx] = shape;
+    Q.h_tri[idx] = tri;
+}
+
+// Reference-shaped traversal of one ray (both modes can use it; the fast mode's kernels
+// use the resumable form instead).
 template <class Stack, bool ORDERED, bool EXACT>
 RT_HD void trace_closest_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, int bounce, uint32_t idx,
                               Stack &stk) {
     RayF ray;
     HitF hit;
-    hit.t = __builtin_inff();
-    hit.shape = -1;
-    hit.tri = -1;
-    int32_t org_shape = -1, org_tri = -1;
-    float tmin;
+    int32_t org_shape, org_tri;
     {
-        D3 o, d;
-        if (bounce == 0) {
-            if (!sample_camera_ray(S, B, idx, o, d)) return;
-            tmin = 1.0f;
-        } else {
-            const int which = bounce & 1;
-            queue_read_ray(Q, which, idx, o, d);
-            org_shape = Q.q_org_shape[which][idx];
-            org_tri = Q.q_org_tri[which][idx];
-            const float self_t = Q.q_self_t[which][idx];
-            if (self_t < hit.t) {
-                hit.t = self_t;
-                hit.shape = org_shape;
-            }
-            tmin = (float)RT_VERY_SMALL_NUMBER;
-        }
-        ray_from_f64(o, d, ray);
+        RaySetup r;
+        if (!closest_setup(S, Q, B, bounce, idx, r)) return;
+        ray_from_f64<EXACT>(r.o, r.d, ray);
+        hit.t = r.t0;
+        hit.shape = r.shape0;
+        hit.tri = -1;
+        org_shape = r.org_shape;
+        org_tri = r.org_tri;
     }
-    if (!traverse<Stack, ORDERED, false, EXACT>(S, ray, tmin, hit, org_shape, org_tri, stk, S.stack_depth))
+    if (!traverse<Stack, ORDERED, false, EXACT>(S, ray, closest_tmin(bounce), hit, org_shape, org_tri, stk, S.stack_depth))
         Q.counters[RT_CNT_OVERFLOW] = 1;
-    Q.h_t[idx] = hit.t;
-    Q.h_shape[idx] = hit.shape;
-    Q.h_tri[idx] = hit.tri;
+    closest_store(Q, idx, hit.t, hit.shape, hit.tri);
+}
+
+// Fast mode, one ray start to finish (what a lane of the persistent kernel does between refills).
+template <class Stack>
+RT_HD void trace_closest_fast_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, int bounce,
+                                   uint32_t idx, Stack &stk) {
+    FastTrav st;
+    {
+        RaySetup r;
+        if (!closest_setup(S, Q, B, bounce, idx, r)) return;
+        fast_begin(S, st, stk, r.o, r.d, r.t0, r.shape0, r.org_shape, r.org_tri);
+    }
+    bool overflow = false;
+    const float tmin = closest_tmin(bounce);
+    while (fast_step<Stack, false>(S, st, stk, tmin, S.stack_depth, overflow)) {
+    }
+    if (overflow) Q.counters[RT_CNT_OVERFLOW] = 1;
+    closest_store(Q, idx, st.t, st.shape, st.tri);
 }
 
 // ---- shade
@@ -269,32 +311,69 @@ RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, co
 }
 
 // ---- trace (shadow): light/point.rs:30-37.  Work item = (point light slot, local sample).
+
+// False when there is nothing to trace (no lit hit, or already known to be blocked).
+template <bool ANYHIT>
+RT_HD bool shadow_setup(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample, RaySetup &r) {
+    r.org_shape = Q.l_shape[sample];
+    if (r.org_shape < 0) return false;
+    const size_t k = (size_t)light_slot * Q.capacity + sample;
+    r.t0 = Q.occ_t[k];  // 1.0 (Hit::to_light), or the origin primitive's own re-hit
+    r.shape0 = Q.occ_shape[k];
+    if (ANYHIT && r.shape0 >= 0) return false;
+    r.org_tri = Q.l_tri[sample];
+    const RtLight &light = S.lights[S.point_lights[light_slot]];
+    r.o = D3{Q.l_p[0][sample], Q.l_p[1][sample], Q.l_p[2][sample]};
+    r.d = d3(light.position) - r.o;  // Ray::atob, ray.rs:15-20
+    return true;
+}
+
+RT_HD void shadow_store(const RtBuffers &Q, uint32_t light_slot, uint32_t sample, int32_t shape, int32_t tri) {
+    const size_t k = (size_t)light_slot * Q.capacity + sample;
+    Q.occ_shape[k] = shape;
+    Q.occ_tri[k] = tri;
+}
+
 template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
 RT_HD void trace_shadow_body(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample,
                              Stack &stk) {
-    const int32_t org_shape = Q.l_shape[sample];
-    if (org_shape < 0) return;
-    const size_t k = (size_t)light_slot * Q.capacity + sample;
-    HitF hit;
-    hit.t = Q.occ_t[k];  // 1.0 (Hit::to_light), or the origin primitive's own re-hit
-    hit.shape = Q.occ_shape[k];
-    hit.tri = -1;
-    if (ANYHIT && hit.shape >= 0) return;  // already known to be blocked
     RayF ray;
+    HitF hit;
+    int32_t org_shape, org_tri;
     {
-        const RtLight &light = S.lights[S.point_lights[light_slot]];
-        const D3 p = D3{Q.l_p[0][sample], Q.l_p[1][sample], Q.l_p[2][sample]};
-        ray_from_f64(p, d3(light.position) - p, ray);  // Ray::atob, ray.rs:15-20
+        RaySetup r;
+        if (!shadow_setup<ANYHIT>(S, Q, light_slot, sample, r)) return;
+        ray_from_f64<EXACT>(r.o, r.d, ray);
+        hit.t = r.t0;
+        hit.shape = r.shape0;
+        hit.tri = -1;
+        org_shape = r.org_shape;
+        org_tri = r.org_tri;
     }
-    if (!traverse<Stack, ORDERED, ANYHIT, EXACT>(S, ray, (float)RT_VERY_SMALL_NUMBER, hit, org_shape, Q.l_tri[sample],
-                                                 stk, S.stack_depth))
+    if (!traverse<Stack, ORDERED, ANYHIT, EXACT>(S, ray, (float)RT_VERY_SMALL_NUMBER, hit, org_shape, org_tri, stk,
+                                                 S.stack_depth))
         Q.counters[RT_CNT_OVERFLOW] = 1;
-    Q.occ_shape[k] = hit.shape;
-    Q.occ_tri[k] = hit.tri;
+    shadow_store(Q, light_slot, sample, hit.shape, hit.tri);
+}
+
+template <class Stack>
+RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample,
+                                  Stack &stk) {
+    FastTrav st;
+    {
+        RaySetup r;
+        if (!shadow_setup<true>(S, Q, light_slot, sample, r)) return;
+        fast_begin(S, st, stk, r.o, r.d, r.t0, r.shape0, r.org_shape, r.org_tri);
+    }
+    bool overflow = false;
+    while (fast_step<Stack, true>(S, st, stk, (float)RT_VERY_SMALL_NUMBER, S.stack_depth, overflow)) {
+    }
+    if (overflow) Q.counters[RT_CNT_OVERFLOW] = 1;
+    shadow_store(Q, light_slot, sample, st.shape, st.tri);
 }
 
 // ---- accumulate: lambertian.rs:17-36 / blinn_phong.rs:23-47.  Returns true if the
-// sample had a lit hit.
+// sample had a lit hit (callers normally only pass such samples).
 RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids,
                            uint32_t sample) {
     const int32_t shape = Q.l_shape[sample];

@@ -17,6 +17,11 @@
 #include <string>
 #include <vector>
 
+// per-thread work tallies, summed by hostsim_tally()
+struct Tally { unsigned long long node = 0, tri = 0, tprim = 0; };
+static thread_local Tally g_tally;
+#define RT_TALLY(what) (++g_tally.what)
+
 #include "../../include/rt_hip.h"
 #include "../../rust-raytracer_amd/csrc/bvh_build.h"
 #include "../../rust-raytracer_amd/csrc/rt_pipeline.h"
@@ -25,8 +30,11 @@ namespace {
 
 struct VecStack {
     std::vector<int32_t> v;
+    float aux[6];
     void set(int i, int32_t x) { v[(size_t)i] = x; }
     int32_t get(int i) const { return v[(size_t)i]; }
+    void set_aux(int i, float x) { aux[i] = x; }
+    float get_aux(int i) const { return aux[i]; }
 };
 
 struct HostScene {
@@ -122,6 +130,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     Q.color = grab<float>(pool, (size_t)cap * 3);
     Q.counters = grab<uint32_t>(pool, RT_CNT_SIZE);
     Q.block_counts = grab<uint32_t>(pool, 1);
+    Q.lit_list = grab<uint32_t>(pool, 1);
     std::memset(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t));
     Q.capacity = cap;
 
@@ -161,8 +170,10 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
             VecStack stk;
             stk.v.assign((size_t)std::max(S.stack_depth, 1), 0);
 #pragma omp for schedule(dynamic, 1024)
-            for (long idx = 0; idx < count; ++idx)
-                trace_closest_body<VecStack, ORDERED, EXACT>(S, Q, B, bounce, (uint32_t)idx, stk);
+            for (long idx = 0; idx < count; ++idx) {
+                if (EXACT) trace_closest_body<VecStack, ORDERED, EXACT>(S, Q, B, bounce, (uint32_t)idx, stk);
+                else trace_closest_fast_body<VecStack>(S, Q, B, bounce, (uint32_t)idx, stk);
+            }
 #pragma omp for schedule(dynamic, 1024)
             for (long idx = 0; idx < count; ++idx) {
                 MirrorTmp tmp;
@@ -185,8 +196,10 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
             if (!S.disable_shadows)
                 for (uint32_t l = 0; l < npl; ++l) {
 #pragma omp for schedule(dynamic, 1024)
-                    for (long e = 0; e < n_samples; ++e)
-                        trace_shadow_body<VecStack, ORDERED, ANYHIT, EXACT>(S, Q, l, (uint32_t)e, stk);
+                    for (long e = 0; e < n_samples; ++e) {
+                        if (EXACT) trace_shadow_body<VecStack, ORDERED, ANYHIT, EXACT>(S, Q, l, (uint32_t)e, stk);
+                        else trace_shadow_fast_body<VecStack>(S, Q, l, (uint32_t)e, stk);
+                    }
                 }
 #pragma omp for schedule(dynamic, 1024) reduction(+ : lit)
             for (long e = 0; e < n_samples; ++e) lit += accumulate_body(S, Q, B, io, (uint32_t)e) ? 1 : 0;
@@ -206,6 +219,23 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
 }
 
 }  // namespace
+
+// Nodes fetched / triangles tested / top-level primitives visited since the last call, over all threads.
+static unsigned long long g_total[3];
+static void tally_flush() {
+#pragma omp parallel
+    {
+#pragma omp critical
+        {
+            g_total[0] += g_tally.node; g_total[1] += g_tally.tri; g_total[2] += g_tally.tprim;
+            g_tally = Tally();
+        }
+    }
+}
+extern "C" void hostsim_tally(unsigned long long out[3]) {
+    tally_flush();
+    for (int k = 0; k < 3; ++k) { out[k] = g_total[k]; g_total[k] = 0; }
+}
 
 extern "C" int hostsim_render(const RtScene *scene, const RtRenderArgs *args, float *fb, const RtRayIds *ids,
                               RtStats *stats) {
@@ -259,11 +289,21 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
             hit.shape = os;
         }
         RayF ray;
-        ray_from_f64(ro, rd, ray);
+        if (mode == RT_MODE_REFERENCE_ORDER) ray_from_f64<true>(ro, rd, ray);
+        else ray_from_f64<false>(ro, rd, ray);
         if (mode == RT_MODE_REFERENCE_ORDER)
             ok = traverse<VecStack, false, false, true>(hs.view, ray, (float)tmin[r], hit, os, ot, stk, hs.view.stack_depth);
-        else
-            ok = traverse<VecStack, true, false, false>(hs.view, ray, (float)tmin[r], hit, os, ot, stk, hs.view.stack_depth);
+        else {
+            FastTrav st;
+            fast_begin(hs.view, st, stk, ro, rd, hit.t, hit.shape, os, ot);
+            bool overflow = false;
+            while (fast_step<VecStack, false>(hs.view, st, stk, (float)tmin[r], hs.view.stack_depth, overflow)) {
+            }
+            ok = !overflow;
+            hit.t = st.t;
+            hit.shape = st.shape;
+            hit.tri = st.tri;
+        }
         if (!ok) return -2;
         t_out[r] = hit.t;
         shape_out[r] = hit.shape;

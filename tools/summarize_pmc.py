@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 outputs of tools/gpu_profile.sh: per kernel, the mean of
+every collected counter per launch, the kernel-trace durations, and derived figures
+(VALU lane utilisation, L2 hit rate, HBM bytes with the gfx950 FETCH_SIZE correction).
+
+    python3 tools/summarize_pmc.py gpurun_out/prof_<tag> [--json out.json]
+"""
+from __future__ import annotations
+
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    m = re.search(r"(k_\w+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+
+
+def main():
+    root = sys.argv[1]
+    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    counters = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values per dispatch
+    for path in glob.glob(os.path.join(root, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+        per_dispatch = defaultdict(float)
+        names = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                key = (row["Dispatch_Id"], row["Counter_Name"])
+                per_dispatch[key] += float(row["Counter_Value"])
+                names[row["Dispatch_Id"]] = short(row["Kernel_Name"])
+        for (disp, cname), val in per_dispatch.items():
+            counters[names[disp]][cname].append(val)
+    durations = {}
+    for path in glob.glob(os.path.join(root, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                durations[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
+                                                 "percent": float(row["Percentage"])}
+    summary = {}
+    for kernel in sorted(set(counters) | set(durations)):
+        if not kernel.startswith("k_"):
+            continue
+        c = {k: sum(v) / len(v) for k, v in counters.get(kernel, {}).items()}
+        d = dict(durations.get(kernel, {}))
+        d["counters"] = c
+        derived = {}
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            # lanes that did work per issued VALU instruction, out of 64
+            derived["valu_lane_utilisation"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU"):
+            derived["valu_busy_per_sq_busy"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CYCLES"]
+        if c.get("SQ_WAVE_CYCLES"):
+            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM",
+                      "SQ_ACTIVE_INST_LDS"):
+                if k in c:
+                    derived[k.lower() + "_per_wave_cycle"] = c[k] / c["SQ_WAVE_CYCLES"]
+        if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
+            derived["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+            # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
+            fetch = c.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+            write = c.get("WRITE_SIZE", 0.0) * 1024.0
+            derived["hbm_read_bytes"] = fetch
+            derived["hbm_write_bytes"] = write
+            if d.get("avg_us"):
+                derived["hbm_gbs"] = (fetch + write) / (d["avg_us"] * 1e-6) / 1e9
+        d["derived"] = derived
+        summary[kernel] = d
+    for kernel, d in summary.items():
+        print(f"== {kernel}: {d.get('calls', '?')} calls, avg {d.get('avg_us', float('nan')):.1f} us, {d.get('percent', 0):.1f} %")
+        for k, v in sorted(d["counters"].items()):
+            print(f"     {k:28s} {v:16.1f}")
+        for k, v in sorted(d["derived"].items()):
+            print(f"   * {k:34s} {v:14.4f}")
+    if out_json:
+        with open(out_json, "w") as f:
+            json.dump(summary, f, indent=1)
+            f.write("\n")
+
+
+if __name__ == "__main__":
+    main()
