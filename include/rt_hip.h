@@ -104,8 +104,11 @@ typedef struct RtRenderArgs {
     int32_t antialias_method;     /* render.rs:10 */
     int32_t mode;                 /* RT_MODE_* */
     /* Image partition for multi-GPU rendering.  The image is cut into
-     * tile_w x tile_h tiles, numbered row-major; tile k of tile-row r belongs
-     * to part (k + r) % part_count.  part_count <= 1 renders everything. */
+     * tile_w x tile_h tiles, numbered row-major, and dealt round-robin: tile k
+     * belongs to part k % part_count, or (k + r) % part_count for tile-row r when
+     * a row holds a multiple of part_count tiles (so that no part owns whole
+     * columns).  Part sizes differ by at most one tile; rt_partition_tiles lists
+     * them.  part_count <= 1 renders everything. */
     uint32_t tile_w, tile_h;      /* 0 -> 32 */
     uint32_t part_index, part_count;
 } RtRenderArgs;
@@ -171,6 +174,11 @@ int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const R
  * edge. */
 int rt_partition_info(uint32_t width, uint32_t height, const RtRenderArgs *args, uint32_t *tiles_total,
                       uint32_t *tiles_owned, uint32_t *tiles_owned_max);
+
+/* The row-major tile indices owned by args->part_index, ascending: slot s of that part's
+ * compact framebuffer holds tile tiles_out[s].  tiles_out may be NULL to query the count. */
+int rt_partition_tiles(uint32_t width, uint32_t height, const RtRenderArgs *args, int32_t *tiles_out,
+                       uint32_t capacity, uint32_t *count_out);
 
 /* Rebuilds the full framebuffer (framebuffer.rs:21-31 layout) on the device from the
  * compact framebuffers of all parts laid end to end: `gathered_dev` holds

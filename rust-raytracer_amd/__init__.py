@@ -224,6 +224,8 @@ def lib() -> C.CDLL:
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
     L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rt_partition_tiles.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, C.c_uint32,
+                                     C.POINTER(C.c_uint32)]
     L.rt_untile_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, vp, vp]
     L.rt_framebuffer_to_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.rt_scene_point_light_count.argtypes = [vp]
@@ -235,6 +237,15 @@ def lib() -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != RT_OK:
         raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
+
+
+def partition_tiles(width: int, height: int, args: "RtRenderArgs") -> np.ndarray:
+    """Tile indices owned by args.part_index (rt_partition_tiles); host-only, needs no GPU."""
+    n = C.c_uint32()
+    _check(lib().rt_partition_tiles(width, height, C.byref(args), None, 0, C.byref(n)))
+    out = np.empty(n.value, np.int32)
+    _check(lib().rt_partition_tiles(width, height, C.byref(args), out.ctypes.data, n.value, C.byref(n)))
+    return out
 
 
 class Scene:

@@ -366,13 +366,13 @@ uint32_t grid_for(uint64_t work) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, RT_MAX_GRID));
 }
 
-// Tiles owned by `part` of `parts`: tile k in tile-row r belongs to (k + r) % parts.
+// Tiles owned by `part` of `parts` (rt_tile_owner), ascending.
 void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t parts, std::vector<int32_t> &out) {
     out.clear();
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
         for (uint32_t tx = 0; tx < tiles_x; ++tx) {
             const uint32_t k = ty * tiles_x + tx;
-            if (parts <= 1 || (k + ty) % parts == part) out.push_back((int32_t)k);
+            if (rt_tile_owner(k, ty, tiles_x, parts) == part) out.push_back((int32_t)k);
         }
 }
 
@@ -433,6 +433,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     if (tile_samples > (1ull << 30)) return rt::set_error(RT_ERR_INVALID, "tile too large");
     if (ds->view.recursion_depth > 30) return rt::set_error(RT_ERR_INVALID, "recursion depth above 30");
 
+    const size_t lds_bytes =
+        (size_t)(std::max(ds->view.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
+    if (lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
+
     RT_HIP(hipSetDevice(be->device));
     if (!stream) stream = be->stream;
 
@@ -481,8 +485,6 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         RT_HIP(hipEventCreate(&ev1));
         RT_HIP(hipEventRecord(ev0, stream));
     }
-    const size_t lds_bytes = (size_t)(std::max(S.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
-    if (lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
     const bool ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
     uint32_t xcd_chunk = 128;
     if (const char *e = std::getenv("RT_XCD_CHUNK")) xcd_chunk = (uint32_t)std::max(1, std::atoi(e));
@@ -811,10 +813,26 @@ extern "C" int rt_partition_info(uint32_t width, uint32_t height, const RtRender
     const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
     std::vector<uint32_t> per_part(parts, 0);
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
-        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[parts <= 1 ? 0 : (ty * tiles_x + tx + ty) % parts]++;
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_owner(ty * tiles_x + tx, ty, tiles_x, parts)]++;
     if (tiles_total) *tiles_total = tiles_x * tiles_y;
     if (tiles_owned) *tiles_owned = per_part[args->part_index];
     if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());
+    return RT_OK;
+}
+
+extern "C" int rt_partition_tiles(uint32_t width, uint32_t height, const RtRenderArgs *args, int32_t *tiles_out,
+                                  uint32_t capacity, uint32_t *count_out) {
+    if (!args || !count_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    std::vector<int32_t> tiles;
+    owned_tiles((width + tw - 1) / tw, (height + th - 1) / th, args->part_index, parts, tiles);
+    *count_out = (uint32_t)tiles.size();
+    if (tiles_out) {
+        if (capacity < tiles.size()) return rt::set_error(RT_ERR_INVALID, "tile buffer too small");
+        std::memcpy(tiles_out, tiles.data(), tiles.size() * sizeof(int32_t));
+    }
     return RT_OK;
 }
 
@@ -834,7 +852,7 @@ extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, 
         std::vector<uint32_t> where((size_t)tiles_x * tiles_y), next(parts, 0);
         for (uint32_t ty = 0; ty < tiles_y; ++ty)
             for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-                const uint32_t k = ty * tiles_x + tx, p = parts <= 1 ? 0 : (k + ty) % parts;
+                const uint32_t k = ty * tiles_x + tx, p = rt_tile_owner(k, ty, tiles_x, parts);
                 where[k] = p * stride + next[p]++;
             }
         if (be->tile_where) (void)hipFree(be->tile_where);

@@ -36,6 +36,15 @@ RT_TYPES_INL int32_t rt_make_leaf_ref(uint32_t first, uint32_t count) {
     return ~(int32_t)((first << 3) | count);
 }
 
+// Owner of tile k = ty * tiles_x + tx in a frame split over `parts` devices.  Tiles are dealt
+// round-robin in row-major order, so part sizes differ by at most one tile; when a tile row holds
+// a whole number of rounds the deal is shifted by one per row, which keeps a part from owning
+// whole columns of the image.
+RT_TYPES_INL uint32_t rt_tile_owner(uint32_t k, uint32_t ty, uint32_t tiles_x, uint32_t parts) {
+    if (parts <= 1) return 0;
+    return (k + (tiles_x % parts == 0 ? ty : 0u)) % parts;
+}
+
 // Top-level primitive, 64 bytes, stored in leaf order of the scene-level tree.
 //   SPHERE    f[0..2] center, f[3] radius
 //   BOX       f[0..2] min, f[3..5] max

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/render_<scene>.npz: the CPU oracle's framebuffer, per-sample ids and ray
+counts for every test scene at 64x48, 4 rays per pixel, depth 6.
+
+    python3 tests/golden/make_golden.py
+
+The fixtures come from this repository's own oracle (oracle/rt_oracle.cpp), not from the
+reference program, which cannot be built here.  They let a machine without the oracle's
+build check the GPU path, and they catch unintended changes of the oracle itself.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SCENES = ["simple_sphere_scene", "spheres_and_triangles", "cornell_room", "spheres_1K", "bunny_small", "mixed_features",
+          "mixed_ortho"]
+WIDTH, HEIGHT, SQRT_RPP, DEPTH = 64, 48, 2, 6
+
+
+def main():
+    import oracle_lib as O
+
+    rt = O.rt
+    importlib.import_module("scenes.gen_scenes").ensure_models()
+    for name in SCENES:
+        sc = rt.parse_scene_file(os.path.join(ROOT, "scenes", name + ".json"), image_width=WIDTH, image_height=HEIGHT,
+                                 recursion_depth=DEPTH)
+        fb, ids, cnt = O.render(sc, SQRT_RPP, threads=1)
+        arrays = {f: getattr(ids, f) for f in rt.ID_FIELDS}
+        np.savez_compressed(os.path.join(HERE, f"render_{name}.npz"), fb=fb, rays=np.array(cnt["rays"], np.int64),
+                            shaded_hits=np.int64(cnt["shaded_hits"]), **arrays)
+        print(name, cnt["rays"])
+
+
+if __name__ == "__main__":
+    main()

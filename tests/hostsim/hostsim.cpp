@@ -96,7 +96,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
         for (uint32_t tx = 0; tx < tiles_x; ++tx) {
             const uint32_t k = ty * tiles_x + tx;
-            if (parts <= 1 || (k + ty) % parts == args.part_index) tile_list.push_back((int32_t)k);
+            if (rt_tile_owner(k, ty, tiles_x, parts) == args.part_index) tile_list.push_back((int32_t)k);
         }
     const uint32_t n_slots = (uint32_t)tile_list.size();
     const uint32_t cap = n_slots * tw * th * spp;

@@ -1,0 +1,124 @@
+"""The C boundary: every entry point declared in include/rt_hip.h is exported by the built
+library, the ctypes mirrors have the C layout, host-only entry points work without a GPU, and
+device entry points fail loudly (no CPU fallback) when there is none."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rt_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(rt):
+    names = declared_functions()
+    assert len(names) >= 15, names
+    L = rt.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/rt_hip.h but not exported by {rt.LIB_PATH}"
+
+
+def test_ctypes_mirrors_have_the_c_layout(rt, tmp_path):
+    structs = {"RtVec3": rt.RtVec3, "RtCamera": rt.RtCamera, "RtShader": rt.RtShader, "RtLight": rt.RtLight,
+               "RtShape": rt.RtShape, "RtMesh": rt.RtMesh, "RtScene": rt.RtScene, "RtParseArgs": rt.RtParseArgs,
+               "RtRenderArgs": rt.RtRenderArgs, "RtRayIds": rt.RtRayIds, "RtStats": rt.RtStats}
+    src = tmp_path / "sz.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_hip.h"', "int main(void){"]
+    for n in structs:
+        lines.append(f'printf("{n} %zu\\n", sizeof({n}));')
+    for field in ("shapes", "lights", "n_lights", "background"):
+        lines.append(f'printf("RtScene.{field} %zu\\n", offsetof(RtScene, {field}));')
+    for field in ("inv_transform", "bbox_max"):
+        lines.append(f'printf("RtShape.{field} %zu\\n", offsetof(RtShape, {field}));')
+    lines.append("return 0;}")
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])  # header is plain C
+    out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for n, s in structs.items():
+        assert C.sizeof(s) == int(out[n]), n
+    for key, val in out.items():
+        if "." in key:
+            sname, field = key.split(".")
+            assert getattr(structs[sname], field).offset == int(val), key
+
+
+def test_host_only_entry_points_need_no_gpu(rt):
+    a = rt.RtRenderArgs()
+    a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count = 3, 40, 40, 1, 8
+    total, owned, owned_max = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = rt.lib().rt_partition_info(1000, 1000, C.byref(a), C.byref(total), C.byref(owned), C.byref(owned_max))
+    assert rc == rt.RT_OK and total.value == 625 and owned_max.value == 79
+    tiles = rt.partition_tiles(1000, 1000, a)
+    assert tiles.size == owned.value
+    fb = rt.Framebuffer(2, 1)
+    fb.pixels[0, 1] = [1.0, 0.5, 0.0]
+    assert fb.to_rgb8().tolist() == [[[0, 0, 0], [255, 128, 0]]]
+    # invalid arguments are reported, not crashed on
+    a.part_index = 9
+    assert rt.lib().rt_partition_info(1000, 1000, C.byref(a), C.byref(total), C.byref(owned), C.byref(owned_max)) == rt.RT_ERR_INVALID
+    assert b"part" in rt.lib().rt_last_error()
+
+
+def test_partition_is_balanced_and_interleaved(rt):
+    """Round-robin deal: part sizes differ by at most one tile, every part has tiles in every tile
+    row and (when there are enough columns) every tile column of the image."""
+    for width, tile in ((1000, 40), (1024, 32), (640, 40)):
+        tiles_x = (width + tile - 1) // tile
+        for parts in (2, 3, 4, 8):
+            counts = []
+            everything = []
+            for p in range(parts):
+                a = rt.RtRenderArgs()
+                a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count = 3, tile, tile, p, parts
+                t = rt.partition_tiles(width, width, a)
+                counts.append(t.size)
+                everything.append(t)
+                assert (np.diff(t) > 0).all()
+                assert len(set((t // tiles_x).tolist())) == tiles_x  # present in every tile row
+                assert len(set((t % tiles_x).tolist())) == tiles_x  # and in every tile column
+            assert max(counts) - min(counts) <= 1, (width, tile, parts, counts)
+            assert sorted(np.concatenate(everything).tolist()) == list(range(tiles_x * tiles_x))
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_device_entry_points_fail_loudly_without_gpu(rt, scene_path):
+    with pytest.raises(rt.RtError) as e:
+        rt.Backend(0)
+    assert e.value.code == rt.RT_ERR_DEVICE
+    sc = rt.parse_scene_file(scene_path("simple_sphere_scene"))
+    with pytest.raises(rt.RtError):
+        rt.render(sc, 1)
+
+
+def test_missing_library_is_an_error_not_a_fallback(tmp_path):
+    code = ("import importlib, os\n"
+            "os.environ['RT_HIP_LIB'] = '%s'\n"
+            "rt = importlib.import_module('rust-raytracer_amd')\n"
+            "try:\n    rt.parse_scene('{}', '')\nexcept rt.RtError as e:\n    print('ERR', e.code)\n" % (tmp_path / "nope.so"))
+    out = subprocess.check_output(["python3", "-c", code], cwd=ROOT).decode()
+    assert "ERR -4" in out
+
+
+def test_product_does_not_reach_into_the_oracle(rt):
+    """The shipped library and package must not link, import or name the test oracle."""
+    deps = subprocess.check_output(["ldd", rt.LIB_PATH]).decode()
+    assert "oracle" not in deps and "hostsim" not in deps
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", rt.LIB_PATH]).decode()
+    assert "oracle_" not in syms and "hostsim_" not in syms
+    pkg = os.path.join(ROOT, "rust-raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle/" not in text and "oracle_lib" not in text and "liboracle" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,83 @@
+"""The shipped BVH builder (csrc/bvh_build.cpp) must produce the reference's tree
+(raytracer-lib/src/geometry/bvh.rs:21-138): same pre-order node sequence, same leaf
+contents in the same order, same f64 boxes.  The oracle builds its tree independently,
+recursively, the way BVH::new does; the product builds into flat arrays."""
+import numpy as np
+import pytest
+
+import hostsim_lib as HS
+import oracle_lib as O
+
+SCENES = ["simple_sphere_scene", "spheres_and_triangles", "cornell_room", "spheres_1K", "bunny_small", "mixed_features",
+          "mixed_ortho"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_level_tree_matches(rt, scene_path, name):
+    sc = rt.parse_scene_file(scene_path(name))
+    ko, po, bo = O.bvh_dump(sc, -1)
+    kp, pp, bp, depth = HS.bvh_dump(sc, -1)
+    assert np.array_equal(ko, kp)
+    assert np.array_equal(po, pp)
+    assert np.array_equal(bo, bp)
+    assert sorted(po.tolist()) == list(range(sc.c.n_shapes))  # every shape exactly once
+    assert (ko[ko > 0] <= 4).all()  # BVH leaf size (bvh.rs:46)
+
+
+@pytest.mark.parametrize("name", ["bunny_small", "bunny_medium", "mixed_features"])
+def test_mesh_tree_matches(rt, scene_path, name):
+    sc = rt.parse_scene_file(scene_path(name))
+    for m in range(sc.c.n_meshes):
+        ko, po, bo = O.bvh_dump(sc, m)
+        kp, pp, bp, depth = HS.bvh_dump(sc, m)
+        assert np.array_equal(ko, kp) and np.array_equal(po, pp) and np.array_equal(bo, bp)
+        assert sorted(po.tolist()) == list(range(sc.c.meshes[m].n_triangles))
+
+
+def test_split_axis_cycles_and_sort_is_stable(rt):
+    """Eight unit spheres whose centroids tie on y and z: the x split must keep file order among
+    equal keys (Vec::sort_by is stable, bvh.rs:75-82), and depth d splits on axis d % 3."""
+    import json
+
+    shapes = [{"_name": f"s{i}", "_type": "sphere", "shader": "m", "center": f"{i % 2} 0 0", "radius": 0.25} for i in range(8)]
+    scene = json.dumps({"scene": {
+        "camera": [{"_name": "main", "_type": "perspective", "position": "0 0 5", "viewDir": "0 0 -1", "focalLength": 1.0}],
+        "shader": [{"_name": "m", "_type": "Lambertian", "diffuse": "1 1 1"}], "shape": shapes}})
+    sc = rt.parse_scene(scene, "")
+    ko, po, bo = O.bvh_dump(sc, -1)
+    kp, pp, bp, _ = HS.bvh_dump(sc, -1)
+    assert np.array_equal(ko, kp) and np.array_equal(po, pp) and np.array_equal(bo, bp)
+    # root splits on x: the four x = 0 spheres (even file indices, in file order) go left
+    assert po.tolist() == [0, 2, 4, 6, 1, 3, 5, 7]
+    assert ko.tolist() == [-1, 4, 4]
+
+
+def test_stack_depth_bounds_the_walk(rt, scene_path):
+    """stack_depth must cover the deepest scene-level path plus the deepest mesh path."""
+    for name in ["bunny_small", "spheres_1K", "mixed_features"]:
+        sc = rt.parse_scene_file(scene_path(name))
+
+        def depth_of(kinds):
+            # pre-order walk: inner = -1 has two children
+            best, stack, d = 0, [], 0
+            it = iter(kinds.tolist())
+
+            def rec(level):
+                nonlocal best
+                k = next(it)
+                best = max(best, level)
+                if k < 0:
+                    rec(level + 1)
+                    rec(level + 1)
+
+            rec(0)
+            return best
+
+        import sys
+
+        sys.setrecursionlimit(10000)
+        k_top, _, _, stack_depth = HS.bvh_dump(sc, -1)
+        need = depth_of(k_top)
+        mesh = max([depth_of(HS.bvh_dump(sc, m)[0]) for m in range(sc.c.n_meshes)] or [0])
+        assert stack_depth >= need + mesh + 1
+        assert stack_depth <= need + mesh + 6  # and is not wastefully large (LDS stack rows)

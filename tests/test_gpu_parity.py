@@ -1,4 +1,5 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -11,6 +12,13 @@ pytestmark = pytest.mark.gpu
 
 SCENES = ["simple_sphere_scene", "spheres_and_triangles", "cornell_room", "spheres_1K", "bunny_small",
           "mixed_features", "mixed_ortho"]
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class GoldenIds:
+    def __init__(self, npz, fields):
+        for f in fields:
+            setattr(self, f, npz[f])
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -27,3 +35,161 @@ def test_scene_matches_oracle(rt, backend, scene_path, name, mode):
     for g, r in zip(got, counters["rays"]):
         assert abs(g - r) <= max(2, 1e-4 * r), (got, counters["rays"])
     dev.close()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_matches_committed_fixture(rt, backend, scene_path, name):
+    """Same comparison against tests/golden/render_*.npz, which needs no oracle build on this machine."""
+    g = np.load(os.path.join(GOLDEN, f"render_{name}.npz"))
+    scene = rt.parse_scene_file(scene_path(name), image_width=64, image_height=48, recursion_depth=6)
+    dev = backend.upload(scene)
+    fb, ids, stats = dev.render(2, mode=rt.RT_MODE_REFERENCE_ORDER, want_ids=True)
+    parity.assert_parity(fb.pixels, ids, g["fb"], GoldenIds(g, rt.ID_FIELDS), label=name)
+    dev.close()
+
+
+@pytest.mark.parametrize("kw", [{"disable_shadows": True}, {"render_normals": True}, {"recursion_depth": 0},
+                                {"recursion_depth": 2}])
+def test_scene_arguments(rt, backend, scene_path, kw):
+    """parse_scene's switches (scene/mod.rs:378-387) change what the render does, on both sides alike."""
+    args = dict(image_width=128, image_height=96, recursion_depth=6)
+    args.update(kw)
+    scene = rt.parse_scene_file(scene_path("mixed_features"), **args)
+    dev = backend.upload(scene)
+    ref_fb, ref_ids, counters = oracle_lib.render(scene, 2)
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        fb, ids, stats = dev.render(2, mode=mode, want_ids=True)
+        parity.assert_parity(fb.pixels, ids, ref_fb, ref_ids, occlusion_only=(mode == rt.RT_MODE_FAST), label=str(kw))
+        if kw.get("disable_shadows"):
+            assert stats.shadow_rays == 0
+        if "recursion_depth" in kw:
+            assert ids.bounces.max() <= kw["recursion_depth"]
+    dev.close()
+
+
+def test_render_is_deterministic_and_modes_agree(rt, backend, scene_path):
+    scene = rt.parse_scene_file(scene_path("cornell_room"), image_width=200, image_height=150, recursion_depth=6)
+    dev = backend.upload(scene)
+    a, ia, _ = dev.render(3, want_ids=True)
+    b, ib, _ = dev.render(3, want_ids=True)
+    assert np.array_equal(a.pixels, b.pixels)
+    for f in rt.ID_FIELDS:
+        assert np.array_equal(getattr(ia, f), getattr(ib, f))
+    c, ic, _ = dev.render(3, mode=rt.RT_MODE_REFERENCE_ORDER, want_ids=True)
+    parity.assert_parity(a.pixels, ia, c.pixels, ic, occlusion_only=True, label="fast vs reference order")
+    dev.close()
+
+
+def test_batched_render_equals_single_batch(rt, backend, scene_path):
+    """A frame larger than the ray-queue capacity is rendered in several batches of tiles; pixels must not change."""
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=200, image_height=150, recursion_depth=6)
+    dev = backend.upload(scene)
+    one, ids_one, s_one = dev.render(3, want_ids=True)
+    os.environ["RT_BATCH_SAMPLES"] = str(32 * 32 * 9 * 5)  # five tiles per batch
+    try:
+        many, ids_many, s_many = dev.render(3, want_ids=True)
+    finally:
+        del os.environ["RT_BATCH_SAMPLES"]
+    assert s_many.kernel_launches[rt.KERNEL_CLASSES.index("resolve")] > s_one.kernel_launches[rt.KERNEL_CLASSES.index("resolve")]
+    assert np.array_equal(one.pixels, many.pixels)
+    for f in rt.ID_FIELDS:
+        assert np.array_equal(getattr(ids_one, f), getattr(ids_many, f)), f
+    assert s_one.total_rays() == s_many.total_rays()
+    dev.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, parts):
+    """The multi-GPU protocol on one GPU: every part renders its tiles into a compact device buffer,
+    the buffers are laid end to end as a gather would, rt_untile_device restores the frame."""
+    import torch
+
+    W, H, tile = 250, 170, 16
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    full, _, full_stats = dev.render(2)
+    a = dev.render_args(2, tile=(tile, tile), part=(0, parts))
+    total, owned, stride = dev.partition_info(a)
+    part_floats = stride * tile * tile * 3
+    gathered = torch.zeros(parts * part_floats, dtype=torch.float32, device="cuda")
+    fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fills ran on torch's stream, the renders use the backend's own
+    rays = 0
+    for p in range(parts):
+        a = dev.render_args(2, tile=(tile, tile), part=(p, parts))
+        st = dev.render_device(a, gathered.data_ptr() + p * part_floats * 4, want_stats=True)
+        rays += st.total_rays()
+    dev.untile_device(a, gathered.data_ptr(), fb.data_ptr())
+    torch.cuda.synchronize()
+    got = fb.cpu().numpy().reshape(H, W, 3)
+    assert np.array_equal(got, full.pixels)
+    assert rays == full_stats.total_rays()
+    # host-buffer variant: a part writes only its own tiles of the full-layout image
+    merged = np.zeros_like(full.pixels)
+    for p in range(parts):
+        fbp, _, _ = dev.render(2, tile=(tile, tile), part=(p, parts))
+        merged += fbp.pixels
+    assert np.array_equal(merged, full.pixels)
+    dev.close()
+
+
+def test_trace_rays_matches_oracle(rt, backend, scene_path):
+    """rt_trace_rays (BVH::closest_hit, geometry/bvh.rs:140) on rays that are not camera rays."""
+    scene = rt.parse_scene_file(scene_path("mixed_features"))
+    dev = backend.upload(scene)
+    rng = np.random.default_rng(5)
+    n = 200000
+    o = rng.normal(size=(n, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 12.0
+    d = rng.normal(size=(n, 3)) * 1.5 - o
+    t_o, s_o, tri_o, _ = oracle_lib.trace_rays(scene, o, d, 1e-6, np.inf)
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        t, s, tri = dev.trace_rays(o, d, 1e-6, np.inf, mode=mode)
+        agree = np.mean((s == s_o) & (tri == tri_o))
+        assert agree >= parity.ID_MATCH_MIN, agree
+        both = (s == s_o) & (s >= 0)
+        assert np.allclose(t[both], t_o[both], rtol=2e-5)
+        assert np.isinf(t[s < 0]).all()  # a miss leaves t at tmax
+    # empty input is accepted
+    t, s, tri = dev.trace_rays(np.zeros((0, 3)), np.zeros((0, 3)), 1e-6, np.inf)
+    assert t.size == 0
+    dev.close()
+
+
+def test_headline_workload_matches_oracle_at_full_size(rt, backend, scene_path):
+    """bunny 1000x1000, 9 rays per pixel, depth 6: the benchmark's frame, every sample compared."""
+    scene = rt.parse_scene_file(scene_path("bunny"), image_width=1000, image_height=1000, recursion_depth=6)
+    dev = backend.upload(scene)
+    fb, ids, stats = dev.render(3, want_ids=True)
+    ref_fb, ref_ids, counters = oracle_lib.render(scene, 3, want_ids=True)
+    im, idm = parity.assert_parity(fb.pixels, ids, ref_fb, ref_ids, occlusion_only=True, label="bunny 1000^2")
+    print("bunny 1000^2 parity:", im, idm)
+    assert abs(stats.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
+    dev.close()
+
+
+def test_invalid_arguments_are_errors(rt, backend, scene_path):
+    scene = rt.parse_scene_file(scene_path("simple_sphere_scene"), image_width=32, image_height=32)
+    dev = backend.upload(scene)
+    with pytest.raises(rt.RtError) as e:
+        dev.render(0)
+    assert e.value.code == rt.RT_ERR_INVALID
+    with pytest.raises(rt.RtError) as e:
+        dev.render(2, antialias_method=rt.AntialiasMethod.Jittered)
+    assert e.value.code == rt.RT_ERR_UNSUPPORTED
+    with pytest.raises(rt.RtError):
+        dev.render(2, part=(3, 2))
+    fb, _, _ = dev.render(1)  # the backend is still usable after errors
+    assert fb.pixels.any()
+    dev.close()
+
+
+def test_drop_in_render_function(rt, scene_path):
+    """raytracer_lib::render's shape: render(&scene, sqrt_rpp, aa, cb) -> Framebuffer (render.rs:7-23)."""
+    scene = rt.parse_scene_file(scene_path("simple_sphere_scene"), image_width=64, image_height=48)
+    calls = []
+    fb = rt.render(scene, 2, rt.AntialiasMethod.Normal, lambda: calls.append(1))
+    ref_fb, _, _ = oracle_lib.render(scene, 2, want_ids=False)
+    assert parity.image_metrics(fb.pixels, ref_fb)["max_abs_diff"] <= 1
+    assert fb.width == 64 and fb.height == 48 and calls == [1]
+    assert fb.get_pixel(0, 47).tolist() == pytest.approx([0.198] * 3)
