@@ -54,7 +54,8 @@ def measured_traffic(workload):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
+            entry = json.load(f).get(workload)
+        return entry["bytes"] if entry else None
     except Exception:
         return None
 

@@ -22,7 +22,9 @@
 #include "rt_error.h"
 #include "rt_pipeline.h"
 
+#ifndef RT_BLOCK
 #define RT_BLOCK 256
+#endif
 #define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
 
 namespace {

@@ -3,16 +3,18 @@
 // once per ray, camera rays and shading.
 //
 // Precision split (what runs in which type, and why):
-//   * Everything that runs once per BVH node or per candidate primitive is fp32
-//     and follows the reference's formulas operation by operation
-//     (geometry/bbox.rs:76-125, sphere.rs:58-89, triangle.rs:66-118).
+//   * Everything that runs once per BVH node or per candidate primitive is fp32:
+//     the node test, the sphere / triangle / box candidate tests and the transform
+//     of the ray into an instance's space while searching.  The reference-order
+//     mode follows the reference's formulas operation by operation
+//     (geometry/bbox.rs:76-125, sphere.rs:58-89, triangle.rs:66-118); the fast
+//     mode rearranges them (see FastTrav below).
 //   * Everything that runs once per RAY is f64 and is the reference's own
 //     arithmetic: camera ray generation, the hit point / normal of the winning
-//     primitive, mirror and shadow ray set-up, the instance transforms, and the
-//     test of a secondary ray against the primitive it starts on.  CDNA4's f64
-//     vector rate is half its f32 rate, so this costs a few percent, and it keeps
-//     fp32 error from accumulating along a chain of bounces: each new ray starts
-//     from the same f64 point the reference would use.
+//     primitive (including its instance transform), mirror and shadow ray set-up,
+//     and the test of a secondary ray against the primitive it starts on.  That
+//     costs a few percent and keeps fp32 error from accumulating along a chain of
+//     bounces: each new ray starts from the same f64 point the reference would use.
 //   * A secondary ray starts ON a primitive; whether it re-hits that primitive is
 //     decided by t ~ 1e-16 against t_min = 1e-6 in the reference.  fp32 cannot
 //     resolve that, so traversal skips the origin primitive and the caller tests
@@ -434,9 +436,6 @@ RT_HD bool payload_hit_f32(int32_t type, const rt_f4 &f0, const rt_f4 &f1, const
 template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
 RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32_t org_shape, int32_t org_tri,
                     Stack &stk, int max_sp) {
-#if defined(RT_ABLATE) && RT_ABLATE == 1
-    return true;
-#endif
     const float wox = ray.ox, woy = ray.oy, woz = ray.oz, wdx = ray.dx, wdy = ray.dy, wdz = ray.dz;
     int32_t cur = S.tlas_root;
     int sp = 0;
@@ -477,9 +476,6 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const int32_t gtri = (int32_t)(first + k);
                     if (cur_shape == org_shape && gtri == org_tri) continue;
-#if defined(RT_ABLATE) && RT_ABLATE == 2
-                    continue;
-#endif
                     RT_TALLY(tri);
                     const rt_f4 *tp = S.tris + (size_t)gtri * 3;
                     const rt_f4 f0 = tp[0], f1 = tp[1], f2 = tp[2];

@@ -26,6 +26,15 @@ static thread_local Tally g_tally;
 #include "../../rust-raytracer_amd/csrc/bvh_build.h"
 #include "../../rust-raytracer_amd/csrc/rt_pipeline.h"
 
+// Optional per-ray work recording (nodes fetched, triangles tested), for divergence studies:
+// [0] camera rays per sample, [1] shadow rays per (light, sample); null = off.
+static uint16_t *g_work_nodes[2], *g_work_tris[2];
+extern "C" void hostsim_record_work(uint16_t *primary_nodes, uint16_t *primary_tris, uint16_t *shadow_nodes,
+                                    uint16_t *shadow_tris) {
+    g_work_nodes[0] = primary_nodes; g_work_tris[0] = primary_tris;
+    g_work_nodes[1] = shadow_nodes; g_work_tris[1] = shadow_tris;
+}
+
 namespace {
 
 struct VecStack {
@@ -171,8 +180,13 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
             stk.v.assign((size_t)std::max(S.stack_depth, 1), 0);
 #pragma omp for schedule(dynamic, 1024)
             for (long idx = 0; idx < count; ++idx) {
+                const Tally before = g_tally;
                 if (EXACT) trace_closest_body<VecStack, ORDERED, EXACT>(S, Q, B, bounce, (uint32_t)idx, stk);
                 else trace_closest_fast_body<VecStack>(S, Q, B, bounce, (uint32_t)idx, stk);
+                if (bounce == 0 && g_work_nodes[0]) {
+                    g_work_nodes[0][idx] = (uint16_t)(g_tally.node - before.node);
+                    g_work_tris[0][idx] = (uint16_t)(g_tally.tri - before.tri);
+                }
             }
 #pragma omp for schedule(dynamic, 1024)
             for (long idx = 0; idx < count; ++idx) {
@@ -197,8 +211,13 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
                 for (uint32_t l = 0; l < npl; ++l) {
 #pragma omp for schedule(dynamic, 1024)
                     for (long e = 0; e < n_samples; ++e) {
+                        const Tally before = g_tally;
                         if (EXACT) trace_shadow_body<VecStack, ORDERED, ANYHIT, EXACT>(S, Q, l, (uint32_t)e, stk);
                         else trace_shadow_fast_body<VecStack>(S, Q, l, (uint32_t)e, stk);
+                        if (g_work_nodes[1]) {
+                            g_work_nodes[1][(size_t)l * n_samples + e] = (uint16_t)(g_tally.node - before.node);
+                            g_work_tris[1][(size_t)l * n_samples + e] = (uint16_t)(g_tally.tri - before.tri);
+                        }
                     }
                 }
 #pragma omp for schedule(dynamic, 1024) reduction(+ : lit)

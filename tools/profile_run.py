@@ -31,16 +31,20 @@ def main():
     be = rt.Backend(0)
     dev = be.upload(scene)
     m = rt.RT_MODE_FAST if mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
-    best = None
+    best, best_wall = None, None
     for f in range(frames):
         t0 = time.perf_counter()
         fb, _, st = dev.render(n, mode=m, tile=(tile, tile))
         dt = time.perf_counter() - t0
         if best is None or st.render_ms < best.render_ms:
             best = st
+        best_wall = dt if best_wall is None else min(best_wall, dt)
     k = {rt.KERNEL_CLASSES[i]: round(best.kernel_ms[i], 4) for i in range(len(rt.KERNEL_CLASSES))}
     print(f"{workload} {mode}: best device {best.render_ms:.3f} ms, rays {best.total_rays()}, "
           f"{best.total_rays() / best.render_ms / 1e6:.3f} Grays/s, kernels {k}, checksum {float(np.sum(fb.pixels)):.6f}")
+    # rt_render with a host framebuffer: device work + the copy of the frame over PCIe + per-kernel event timing
+    print(f"{workload} {mode}: best wall time of rt_render into host memory {best_wall * 1e3:.3f} ms, "
+          f"{best.total_rays() / best_wall / 1e9:.3f} Grays/s")
     dev.close()
     be.close()
 

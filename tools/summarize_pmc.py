@@ -81,6 +81,25 @@ def main():
         with open(out_json, "w") as f:
             json.dump(summary, f, indent=1)
             f.write("\n")
+    if "--traffic-json" in sys.argv:
+        # HBM bytes per launch of the kernel with the most device time, for bench.py's roofline.traffic
+        path = sys.argv[sys.argv.index("--traffic-json") + 1]
+        workload = sys.argv[sys.argv.index("--workload") + 1]
+        timed = {k: d for k, d in summary.items() if d.get("avg_us") and "hbm_read_bytes" in d["derived"]}
+        if timed:
+            dom = max(timed, key=lambda k: timed[k]["avg_us"] * timed[k]["calls"])
+            try:
+                with open(path) as f:
+                    table = json.load(f)
+            except Exception:
+                table = {}
+            dd = timed[dom]["derived"]
+            table[workload] = {"kernel": dom, "hbm_read_bytes": dd["hbm_read_bytes"], "hbm_write_bytes": dd["hbm_write_bytes"],
+                               "bytes": dd["hbm_read_bytes"] + dd["hbm_write_bytes"], "avg_us": timed[dom]["avg_us"],
+                               "source": root}
+            with open(path, "w") as f:
+                json.dump(table, f, indent=1)
+                f.write("\n")
 
 
 if __name__ == "__main__":
