@@ -75,6 +75,41 @@ void box_to_f32(const double bmin[3], const double bmax[3], float omin[3], float
     }
 }
 
+void set_child_box(RtNode &rec, bool right, const double bmin[3], const double bmax[3]) {
+    float lo[3], hi[3];
+    box_to_f32(bmin, bmax, lo, hi);
+    float *mn = right ? rec.rmin_xy : rec.lmin_xy, *mx = right ? rec.rmax_xy : rec.lmax_xy, *z = right ? rec.rz : rec.lz;
+    mn[0] = lo[0]; mn[1] = lo[1];
+    mx[0] = hi[0]; mx[1] = hi[1];
+    z[0] = lo[2]; z[1] = hi[2];
+}
+
+// The affine map of a triangle (RtTriXf), from its f64 vertices.
+void triangle_map(const double *v, RtTriXf &out) {
+    const double a[3] = {v[0], v[1], v[2]};
+    const double e1[3] = {v[3] - a[0], v[4] - a[1], v[5] - a[2]};
+    const double e2[3] = {v[6] - a[0], v[7] - a[1], v[8] - a[2]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    if (!(nn > 0.0) || !std::isfinite(nn)) {
+        for (int k = 0; k < 4; ++k) out.u[k] = out.v[k] = out.n[k] = NAN;
+        return;
+    }
+    // rows of [e1 e2 n]^-1:  (e2 x n)/nn,  (n x e1)/nn,  n/nn
+    const double ru[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
+    const double rv[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
+    const double rn[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
+    for (int k = 0; k < 3; ++k) {
+        out.u[k] = (float)ru[k];
+        out.v[k] = (float)rv[k];
+        out.n[k] = (float)rn[k];
+    }
+    // offsets from the ROUNDED rows, so that the map is exact at vertex a for the fp32 rows
+    out.u[3] = (float)-((double)out.u[0] * a[0] + (double)out.u[1] * a[1] + (double)out.u[2] * a[2]);
+    out.v[3] = (float)-((double)out.v[0] * a[0] + (double)out.v[1] * a[1] + (double)out.v[2] * a[2]);
+    out.n[3] = (float)-((double)out.n[0] * a[0] + (double)out.n[1] * a[1] + (double)out.n[2] * a[2]);
+}
+
 // Emits the subtree `t` of `tree` into out.nodes and returns the reference a
 // parent stores for it.  `prim_base` is added to leaf offsets.
 int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes) {
@@ -85,8 +120,8 @@ int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode
     const TreeNode &l = tree.nodes[(size_t)n.left];
     const TreeNode &r = tree.nodes[(size_t)n.right];
     RtNode rec{};
-    box_to_f32(l.bmin, l.bmax, rec.lmin, rec.lmax);
-    box_to_f32(r.bmin, r.bmax, rec.rmin, rec.rmax);
+    set_child_box(rec, false, l.bmin, l.bmax);
+    set_child_box(rec, true, r.bmin, r.bmax);
     nodes[(size_t)me] = rec;
     const int32_t lref = emit(tree, n.left, prim_base, nodes);
     const int32_t rref = emit(tree, n.right, prim_base, nodes);
@@ -101,11 +136,9 @@ int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNod
     const int32_t header = (int32_t)nodes.size();
     nodes.emplace_back();
     RtNode rec{};
-    box_to_f32(tree.nodes[0].bmin, tree.nodes[0].bmax, rec.lmin, rec.lmax);
-    for (int k = 0; k < 3; ++k) {
-        rec.rmin[k] = INFINITY;
-        rec.rmax[k] = -INFINITY;
-    }
+    set_child_box(rec, false, tree.nodes[0].bmin, tree.nodes[0].bmax);
+    rec.rmin_xy[0] = rec.rmin_xy[1] = rec.rz[0] = INFINITY;  // an empty box: nothing enters it
+    rec.rmax_xy[0] = rec.rmax_xy[1] = rec.rz[1] = -INFINITY;
     rec.right = RT_REF_NONE;
     nodes[(size_t)header] = rec;
     const int32_t root_ref = emit(tree, 0, prim_base, nodes);
@@ -248,6 +281,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
 
     // ---- triangles in leaf order
     out.tris.resize((size_t)tri_total);
+    out.tri_xf.resize((size_t)tri_total);
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
         const RtMesh &mesh = scene.meshes[m];
         const Tree &t = out.blas[m];
@@ -263,6 +297,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
             tri.orig = orig;
             tri.mesh = (int32_t)m;
             tri._pad = 0;
+            triangle_map(v, out.tri_xf[(size_t)out.mesh_tri_base[m] + k]);
         }
     }
 

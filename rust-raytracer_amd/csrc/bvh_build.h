@@ -36,6 +36,7 @@ struct FlatScene {
     std::vector<RtTPrim> tprims;
     std::vector<float> tprim_xf;          // 12 floats per tprim: fp32 rows of an instance's inverse transform
     std::vector<RtTri> tris;
+    std::vector<RtTriXf> tri_xf;          // same order as `tris`
     std::vector<uint64_t> mesh_tri_base;  // first entry of `tris` / `verts64` triangle per mesh
     std::vector<double> verts64;          // 9 doubles per triangle, FILE order, meshes concatenated
     int32_t tlas_root = 0;                // header node of the scene-level tree

@@ -21,6 +21,7 @@
 #include "bvh_build.h"
 #include "rt_error.h"
 #include "rt_pipeline.h"
+#include "rt_packet.h"
 
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
@@ -122,6 +123,51 @@ k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_sampl
     if (idx >= count) return;
     if (KIND == 1) trace_shadow_fast_body<LdsStack>(S, Q, blockIdx.y, Q.lit_list[idx], stk);
     else trace_closest_fast_body<LdsStack>(S, Q, B, bounce, idx, stk);
+}
+
+// Packet form of the same two kernels (rt_packet.h): a wave traverses with its 64 rays together.
+// Used for camera rays and shadow rays, whose neighbours in a wave are neighbouring samples.
+// Dynamic LDS: one uniform stack of (stack_depth + 1) dwords per wave.
+template <int KIND>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk) {
+    extern __shared__ int32_t lds[];
+    const uint32_t count = KIND == 1 ? Q.counters[RT_CNT_LIT] : n_samples;
+    const uint32_t n_blocks = (count + RT_BLOCK - 1) / RT_BLOCK;  // blocks that have work; the rest leave
+    if (blockIdx.x >= n_blocks) return;
+    const uint32_t idx = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk) * RT_BLOCK + threadIdx.x;
+    const int rows = S.stack_depth + 1;
+    FastTrav st;
+    RaySetup r;
+    uint32_t sample = 0;
+    bool live = idx < count;
+    if (live) {
+        if (KIND == 1) {
+            sample = Q.lit_list[idx];
+            live = shadow_setup<true>(S, Q, blockIdx.y, sample, r);
+        } else {
+            live = closest_setup(S, Q, B, 0, idx, r);
+        }
+    }
+    if (!live) {  // a lane without a ray: finite dummy values and an empty search interval
+        r.o = D3{0.0, 0.0, 0.0};
+        r.d = D3{0.0, 0.0, -1.0};
+        r.t0 = -__builtin_inff();
+        r.shape0 = -1;
+        r.org_shape = r.org_tri = -1;
+    }
+    fast_set_ray(st, (float)r.o.x, (float)r.o.y, (float)r.o.z, (float)r.d.x, (float)r.d.y, (float)r.d.z);
+    st.t = r.t0;
+    st.shape = r.shape0;
+    st.tri = -1;
+    st.org_shape = r.org_shape;
+    st.org_tri = r.org_tri;
+    const float tmin = KIND == 1 ? (float)RT_VERY_SMALL_NUMBER : closest_tmin(0);
+    const bool ok = packet_traverse<KIND == 1>(S, st, tmin, lds + (threadIdx.x >> 6) * rows, rows - 1);
+    if (!ok) Q.counters[RT_CNT_OVERFLOW] = 1;
+    if (!live) return;
+    if (KIND == 1) shadow_store(Q, blockIdx.y, sample, st.shape, st.tri);
+    else closest_store(Q, idx, st.t, st.shape, st.tri);
 }
 
 // ---- compaction of the lit table into a list of sample indices, in sample order
@@ -492,6 +538,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     if (const char *e = std::getenv("RT_XCD_CHUNK")) xcd_chunk = (uint32_t)std::max(1, std::atoi(e));
     const int max_bounce = ds->has_mirror ? S.recursion_depth : 0;
     std::vector<uint32_t> host_counters;
+    // fast mode: wave packets for camera and shadow rays (RT_PACKET=0 keeps the per-lane kernels, for comparison)
+    bool use_packets = true;
+    if (const char *e = std::getenv("RT_PACKET")) use_packets = std::atoi(e) != 0;
+    const size_t packet_lds = (size_t)(std::max(S.stack_depth, 1) + 1) * (RT_BLOCK / 64) * sizeof(int32_t);
 
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
@@ -515,6 +565,8 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
+            else if (bounce == 0 && use_packets)
+                hipLaunchKernelGGL((k_trace_packet<0>), dim3(fast_grid), dim3(RT_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
             else
                 hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
@@ -535,6 +587,8 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
                 const dim3 sg(full_grid, ds->n_point_lights);
                 if (ref_order)
                     hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
+                else if (use_packets)
+                    hipLaunchKernelGGL((k_trace_packet<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
                 else
                     hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
                 tm.end();
@@ -663,6 +717,7 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
     if ((rc = up(flat.nodes.data(), flat.nodes.size() * sizeof(RtNode), (const void **)&V.nodes))) return fail(rc);
     if ((rc = up(flat.tprims.data(), flat.tprims.size() * sizeof(RtTPrim), (const void **)&V.tprims))) return fail(rc);
     if ((rc = up(flat.tris.data(), flat.tris.size() * sizeof(RtTri), (const void **)&V.tris))) return fail(rc);
+    if ((rc = up(flat.tri_xf.data(), flat.tri_xf.size() * sizeof(RtTriXf), (const void **)&V.tri_xf))) return fail(rc);
     if ((rc = up(flat.tprim_xf.data(), flat.tprim_xf.size() * sizeof(float), (const void **)&V.tprim_xf))) return fail(rc);
     if ((rc = up(scene->shapes, scene->n_shapes * sizeof(RtShape), (const void **)&V.shapes))) return fail(rc);
     if ((rc = up(scene->protos, scene->n_protos * sizeof(RtShape), (const void **)&V.protos))) return fail(rc);

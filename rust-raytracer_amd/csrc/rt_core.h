@@ -46,12 +46,16 @@ struct alignas(16) rt_f4 {
 #ifndef RT_TALLY
 #define RT_TALLY(what)
 #endif
+#ifndef RT_VISIT
+#define RT_VISIT(kind, index)
+#endif
 
 // Everything a kernel needs to know about the uploaded scene; passed by value.
 struct RtSceneView {
     const rt_f4 *nodes;   // 4 per RtNode
     const rt_f4 *tprims;  // 4 per RtTPrim
     const rt_f4 *tris;    // 3 per RtTri
+    const rt_f4 *tri_xf;  // 3 per RtTriXf, same order as tris
     const rt_f4 *tprim_xf;  // 3 per RtTPrim: rows of the instance's inverse transform (fp32), zeros otherwise
     const RtShape *shapes;
     const RtShape *protos;
@@ -447,9 +451,10 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
             const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
             const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
             float el = 0.0f, er = 0.0f;
-            const bool hl = slab_f32<EXACT>(a.x, a.y, a.z, a.w, b.x, b.y, ray, tmin, hit.t, el);
+            // RtNode: a = left (min.x, min.y, max.x, max.y), b = right likewise, c = z planes (l min, l max, r min, r max)
+            const bool hl = slab_f32<EXACT>(a.x, a.y, c.x, a.z, a.w, c.y, ray, tmin, hit.t, el);
             const bool hr =
-                rref != RT_REF_NONE && slab_f32<EXACT>(b.z, b.w, c.x, c.y, c.z, c.w, ray, tmin, hit.t, er);
+                rref != RT_REF_NONE && slab_f32<EXACT>(b.x, b.y, c.z, b.z, b.w, c.w, ray, tmin, hit.t, er);
             if (hl && hr) {
                 const bool swap = ORDERED && er < el;
                 if (sp >= max_sp) return false;
@@ -547,23 +552,73 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
 // It is a resumable state machine (begin / step) so that a kernel can hand a finished
 // lane its next ray while the other lanes of the wave keep traversing.
 
+// Pairs of floats as the packed fp32 instructions (v_pk_fma_f32: two multiply-adds per lane per
+// instruction) take them: an aligned register pair on the device, a plain struct on the host.
+RT_HD float rt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+RT_HD rt_f2 rt_fma2(rt_f2 a, rt_f2 b, rt_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+RT_HD rt_f2 rt_pair(float x, float y) { return rt_f2{x, y}; }
+RT_HD rt_f2 rt_lo2(rt_f2 v) { return __builtin_shufflevector(v, v, 0, 0); }
+RT_HD rt_f2 rt_hi2(rt_f2 v) { return __builtin_shufflevector(v, v, 1, 1); }
+#else
+struct rt_f2 { float x, y; };
+RT_HD rt_f2 rt_fma2(rt_f2 a, rt_f2 b, rt_f2 c) { return rt_f2{rt_fma(a.x, b.x, c.x), rt_fma(a.y, b.y, c.y)}; }
+RT_HD rt_f2 rt_pair(float x, float y) { return rt_f2{x, y}; }
+RT_HD rt_f2 rt_lo2(rt_f2 v) { return rt_f2{v.x, v.x}; }
+RT_HD rt_f2 rt_hi2(rt_f2 v) { return rt_f2{v.y, v.y}; }
+#endif
+
 struct FastTrav {
-    float ox, oy, oz, dx, dy, dz, ix, iy, iz;  // current-space ray and clamped 1/d
-    float t;                                   // search bound / closest hit so far
-    int32_t shape, tri;                        // closest hit so far
-    int32_t cur, sp, cur_shape;                // traversal position
-    int32_t org_shape, org_tri;                // primitive the ray starts on (skipped)
+    float ox, oy, oz, dx, dy, dz;  // current-space ray
+    rt_f2 ixy;                     // clamped 1/d, x and y
+    rt_f2 nxy;                     // -o * (1/d), x and y: a plane p is crossed at t = p * (1/d) + n
+    rt_f2 zin;                     // (1/d.z, -o.z * (1/d.z))
+    float t;                       // search bound / closest hit so far
+    int32_t shape, tri;            // closest hit so far
+    int32_t cur, sp, cur_shape;    // traversal position
+    int32_t tos;                   // top of the traversal stack, kept in a register (RT_REF_NONE = empty)
+    int32_t org_shape, org_tri;    // primitive the ray starts on (skipped)
 };
 
+
+// 1/d limited to +-2^62.  The limit only matters for a ray parallel to a slab (d = 0): the
+// plane distances become +-huge with the sign of (p - o), which is all the slab logic needs,
+// and they stay finite, so that p * (1/d) - o * (1/d) never meets inf - inf.  p == o gives
+// exactly 0 (the limit is a power of two): a ray lying in a box face's plane treats that axis
+// as unconstrained on the entry side, like the reference's 0/0 = NaN comparisons do.
 RT_HD float rt_inv_clamped(float d) {
-    const float big = 3.4028234e38f;
+    const float big = 4611686018427387904.0f;
     const float r = rt_rcp_approx(d);
     return rt_fmin(rt_fmax(r, -big), big);
 }
 
 RT_HD void fast_set_ray(FastTrav &s, float ox, float oy, float oz, float dx, float dy, float dz) {
     s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
-    s.ix = rt_inv_clamped(dx); s.iy = rt_inv_clamped(dy); s.iz = rt_inv_clamped(dz);
+    const float ix = rt_inv_clamped(dx), iy = rt_inv_clamped(dy);
+    s.ixy = rt_pair(ix, iy);
+    s.nxy = rt_pair(-(ox * ix), -(oy * iy));
+    const float iz = rt_inv_clamped(dz);
+    s.zin = rt_pair(iz, -(oz * iz));
+}
+
+// The stack keeps its top entry in a register: a pop hands that out at once and starts the
+// LDS read of the entry below, whose latency is then hidden behind the next node.
+template <class Stack>
+RT_HD void fast_push(FastTrav &s, Stack &stk, int32_t ref) {
+    stk.set(s.sp, s.tos);
+    s.sp += 1;
+    s.tos = ref;
+}
+// (Row 0 always holds the RT_REF_NONE that the first push moved there, so popping the last
+// entry reloads the empty marker without a special case; a pop of the empty stack returns
+// RT_REF_NONE, which ends the traversal, and what it leaves in `tos` is never used.)
+template <class Stack>
+RT_HD int32_t fast_pop(FastTrav &s, Stack &stk) {
+    const int32_t r = s.tos;
+    s.sp = s.sp > 0 ? s.sp - 1 : 0;
+    s.tos = stk.get(s.sp);
+    return r;
 }
 
 // Aux slots 0..5 of the stack object hold the world-space ray while a lane is inside an instance.
@@ -578,38 +633,56 @@ RT_HD void fast_begin(const RtSceneView &S, FastTrav &s, Stack &stk, const D3 &o
     s.tri = -1;
     s.cur = S.tlas_root;
     s.sp = 0;
+    s.tos = RT_REF_NONE;
     s.cur_shape = -1;
     s.org_shape = org_shape;
     s.org_tri = org_tri;
 }
 
-// Entry distance of the ray into a box within (tmin, s.t), or a miss.
+// Entry distance of the ray into a box within (tmin, s.t), or a miss.  The test only culls
+// (primitives decide hits); a box of zero thickness gives entry == exit and is never entered,
+// like the reference's (bbox.rs:89,104,119).
 RT_HD bool fast_box(const FastTrav &s, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tmin,
                     float &entry) {
-    const float t0x = (mnx - s.ox) * s.ix, t1x = (mxx - s.ox) * s.ix;
-    const float t0y = (mny - s.oy) * s.iy, t1y = (mxy - s.oy) * s.iy;
-    const float t0z = (mnz - s.oz) * s.iz, t1z = (mxz - s.oz) * s.iz;
+    const float t0x = rt_fma(mnx, s.ixy.x, s.nxy.x), t1x = rt_fma(mxx, s.ixy.x, s.nxy.x);
+    const float t0y = rt_fma(mny, s.ixy.y, s.nxy.y), t1y = rt_fma(mxy, s.ixy.y, s.nxy.y);
+    const float t0z = rt_fma(mnz, s.zin.x, s.zin.y), t1z = rt_fma(mxz, s.zin.x, s.zin.y);
     const float e = rt_fmax(rt_fmax(rt_fmax(rt_fmin(t0x, t1x), rt_fmin(t0y, t1y)), rt_fmin(t0z, t1z)), tmin);
     const float x = rt_fmin(rt_fmin(rt_fmin(rt_fmax(t0x, t1x), rt_fmax(t0y, t1y)), rt_fmax(t0z, t1z)), s.t);
     entry = e;
     return e < x;
 }
 
-RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &f0, const rt_f4 &f1, const rt_f4 &f2, float tmin, float &t_out) {
-    const float ax = f0.x, ay = f0.y, az = f0.z, abx = f0.w, aby = f1.x, abz = f1.y, acx = f1.z, acy = f1.w, acz = f2.x;
-    // c = ac x d ; det A = det[ab ac d] = ab . c
-    const float cx = acy * s.dz - acz * s.dy, cy = acz * s.dx - acx * s.dz, cz = acx * s.dy - acy * s.dx;
-    const float det_a = abx * cx + aby * cy + abz * cz;
-    if (__builtin_fabsf(det_a) < 2.220446049250313e-16f) return false;
-    const float inv_det = rt_rcp_approx(det_a);
-    const float aox = ax - s.ox, aoy = ay - s.oy, aoz = az - s.oz;
-    // q = ab x ao ; det[ab ac ao] = -(ac . q) ; det[ab ao d] = d . q ; det[ao ac d] = ao . c
-    const float qx = aby * aoz - abz * aoy, qy = abz * aox - abx * aoz, qz = abx * aoy - aby * aox;
-    const float t = -(acx * qx + acy * qy + acz * qz) * inv_det;
+// Both child boxes of a node at once (see rt_f2 above).
+RT_HD void fast_box2(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, const rt_f4 &c, float tmin, float &el, float &er,
+                     bool &hl, bool &hr) {
+    const rt_f2 ixy = s.ixy, nxy = s.nxy, izz = rt_lo2(s.zin), nzz = rt_hi2(s.zin);
+    const rt_f2 l0 = rt_fma2(rt_pair(a.x, a.y), ixy, nxy), l1 = rt_fma2(rt_pair(a.z, a.w), ixy, nxy);
+    const rt_f2 r0 = rt_fma2(rt_pair(b.x, b.y), ixy, nxy), r1 = rt_fma2(rt_pair(b.z, b.w), ixy, nxy);
+    const rt_f2 lz = rt_fma2(rt_pair(c.x, c.y), izz, nzz), rz = rt_fma2(rt_pair(c.z, c.w), izz, nzz);
+    el = rt_fmax(rt_fmax(rt_fmax(rt_fmin(l0.x, l1.x), rt_fmin(l0.y, l1.y)), rt_fmin(lz.x, lz.y)), tmin);
+    const float xl = rt_fmin(rt_fmin(rt_fmin(rt_fmax(l0.x, l1.x), rt_fmax(l0.y, l1.y)), rt_fmax(lz.x, lz.y)), s.t);
+    er = rt_fmax(rt_fmax(rt_fmax(rt_fmin(r0.x, r1.x), rt_fmin(r0.y, r1.y)), rt_fmin(rz.x, rz.y)), tmin);
+    const float xr = rt_fmin(rt_fmin(rt_fmin(rt_fmax(r0.x, r1.x), rt_fmax(r0.y, r1.y)), rt_fmax(rz.x, rz.y)), s.t);
+    hl = el < xl;
+    hr = er < xr;
+}
+
+// Triangle::closest_hit (triangle.rs:66-110) through the triangle's affine map (RtTriXf):
+// t from the height row, then beta and gamma of the point at t.  Same acceptance rules:
+// t in [tmin, bound] closed, gamma in [0, 1], beta in [0, 1 - gamma]; a ray parallel to the
+// plane gives t = inf or NaN and fails the range test, as |det A| < epsilon does there.
+RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &u, const rt_f4 &v, const rt_f4 &n, float tmin, float &t_out) {
+    const float hn = rt_fma(n.x, s.ox, rt_fma(n.y, s.oy, rt_fma(n.z, s.oz, n.w)));
+    const float dn = rt_fma(n.x, s.dx, rt_fma(n.y, s.dy, n.z * s.dz));
+    const float t = -hn * rt_rcp_approx(dn);
     if (!(t >= tmin && t <= s.t)) return false;
-    const float gamma = (s.dx * qx + s.dy * qy + s.dz * qz) * inv_det;
+    const float ou = rt_fma(u.x, s.ox, rt_fma(u.y, s.oy, rt_fma(u.z, s.oz, u.w)));
+    const float du = rt_fma(u.x, s.dx, rt_fma(u.y, s.dy, u.z * s.dz));
+    const float ov = rt_fma(v.x, s.ox, rt_fma(v.y, s.oy, rt_fma(v.z, s.oz, v.w)));
+    const float dv = rt_fma(v.x, s.dx, rt_fma(v.y, s.dy, v.z * s.dz));
+    const float beta = rt_fma(t, du, ou), gamma = rt_fma(t, dv, ov);
     if (!(gamma >= 0.0f && gamma <= 1.0f)) return false;
-    const float beta = (aox * cx + aoy * cy + aoz * cz) * inv_det;
     if (!(beta >= 0.0f && beta <= 1.0f - gamma)) return false;
     t_out = t;
     return true;
@@ -621,29 +694,31 @@ template <class Stack, bool ANYHIT>
 RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, int max_sp, bool &overflow) {
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
     int32_t cur = s.cur;
-    int sp = s.sp;
     while (cur >= 0) {
         RT_TALLY(node);
+        RT_VISIT(0, cur);
         const rt_f4 *n = reinterpret_cast<const rt_f4 *>(node_base + ((uint32_t)cur << 6));
+        // a = left (min.x, min.y, max.x, max.y), b = right likewise, c = z planes (l min, l max, r min, r max)
         const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
         const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
         float el, er;
-        const bool hl = fast_box(s, a.x, a.y, a.z, a.w, b.x, b.y, tmin, el);
-        const bool hr = fast_box(s, b.z, b.w, c.x, c.y, c.z, c.w, tmin, er) && rref != RT_REF_NONE;
+        bool hl, hr;
+        fast_box2(s, a, b, c, tmin, el, er, hl, hr);
+        hr = hr && rref != RT_REF_NONE;
         if (hl && hr) {
             const bool swap = er < el;
-            if (sp >= max_sp) { overflow = true; return false; }
-            stk.set(sp++, swap ? lref : rref);
+            if (s.sp >= max_sp) { overflow = true; return false; }
+            fast_push(s, stk, swap ? lref : rref);
             cur = swap ? rref : lref;
         } else if (hl) {
             cur = lref;
         } else if (hr) {
             cur = rref;
         } else {
-            cur = sp > 0 ? stk.get(--sp) : RT_REF_NONE;
+            cur = fast_pop(s, stk);
         }
     }
-    if (cur == RT_REF_NONE) { s.cur = cur; s.sp = sp; return false; }
+    if (cur == RT_REF_NONE) { s.cur = cur; return false; }
     bool entered = false;
     if (cur == RT_REF_EXIT_BLAS) {
         fast_set_ray(s, stk.get_aux(0), stk.get_aux(1), stk.get_aux(2), stk.get_aux(3), stk.get_aux(4), stk.get_aux(5));
@@ -652,11 +727,12 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
         const uint32_t v = (uint32_t)~cur;
         const uint32_t cnt = v & 7u, first = v >> 3;
         if (s.cur_shape >= 0) {
-            const char *tri_base = reinterpret_cast<const char *>(S.tris);
+            const char *tri_base = reinterpret_cast<const char *>(S.tri_xf);
             for (uint32_t k = 0; k < cnt; ++k) {
                 const int32_t gtri = (int32_t)(first + k);
                 if (s.cur_shape == s.org_shape && gtri == s.org_tri) continue;
                 RT_TALLY(tri);
+                RT_VISIT(1, gtri);
                 const rt_f4 *tp = reinterpret_cast<const rt_f4 *>(tri_base + (uint32_t)gtri * 48u);
                 float t;
                 if (fast_triangle(s, tp[0], tp[1], tp[2], tmin, t)) {
@@ -682,9 +758,9 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
                         float e;
                         if (!fast_box(s, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e)) continue;
                     }
-                    if (sp + 2 > max_sp) { overflow = true; return false; }
-                    if (k + 1 < cnt) stk.set(sp++, rt_make_leaf_ref(first + k + 1, cnt - k - 1));
-                    stk.set(sp++, RT_REF_EXIT_BLAS);
+                    if (s.sp + 2 > max_sp) { overflow = true; return false; }
+                    if (k + 1 < cnt) fast_push(s, stk, rt_make_leaf_ref(first + k + 1, cnt - k - 1));
+                    fast_push(s, stk, RT_REF_EXIT_BLAS);
                     if (is_inst) {
                         const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
                         const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
@@ -715,9 +791,8 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
             }
         }
     }
-    if (!entered) cur = sp > 0 ? stk.get(--sp) : RT_REF_NONE;
+    if (!entered) cur = fast_pop(s, stk);
     s.cur = cur;
-    s.sp = sp;
     return cur != RT_REF_NONE;
 }
 

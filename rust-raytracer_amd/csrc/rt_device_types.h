@@ -15,9 +15,16 @@
 //                           (first indexes the top-level primitive table, or the
 //                           triangle table while inside a mesh)
 //   ref == RT_REF_NONE      no child (only in a tree's header node)
+//
+// Plane order: the x and y planes of both boxes come first, in (min.x, min.y) / (max.x, max.y)
+// pairs, the four z planes last.  A ray then needs its (1/d.x, 1/d.y) pair for the first four
+// register pairs of the record and 1/d.z for the last two, which is the operand shape of the
+// packed fp32 multiply-add (two planes per instruction).
 struct RtNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
+    float lmin_xy[2], lmax_xy[2];
+    float rmin_xy[2], rmax_xy[2];
+    float lz[2];  // left box min.z, max.z
+    float rz[2];  // right box min.z, max.z
     int32_t left, right;
     int32_t _pad[2];
 };
@@ -59,6 +66,16 @@ struct RtTPrim {
     float f[12];
 };
 static_assert(sizeof(RtTPrim) == 64, "RtTPrim must be 64 bytes");
+
+// The same triangle as an affine map, 48 bytes, same order as RtTri: for a point p,
+//   beta(p)  = u . (p, 1)     gamma(p) = v . (p, 1)     height(p) = n . (p, 1)
+// are its coordinates in the frame (b - a, c - a, (b - a) x (c - a)) at a, i.e. the solution of
+// triangle.rs:76-105's linear system without the per-ray determinants.  A degenerate
+// triangle (the reference's det A == 0, never hit) stores NaN rows.
+struct RtTriXf {
+    float u[4], v[4], n[4];
+};
+static_assert(sizeof(RtTriXf) == 48, "RtTriXf must be 48 bytes");
 
 // Mesh triangle, 48 bytes, stored in leaf order of its mesh's tree.
 struct RtTri {

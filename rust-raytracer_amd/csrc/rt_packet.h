@@ -1,0 +1,165 @@
+// rt_packet.h -- wave-packet traversal for coherent rays (gfx950 device code only).
+//
+// The 64 rays of a wavefront walk the tree TOGETHER: the current node, the stack and the
+// position inside a leaf are wave-uniform (scalar registers, one small LDS stack per wave),
+// node and triangle records are fetched once per wave through the scalar cache instead of once
+// per lane through the vector memory pipeline, and every branch is a scalar branch.  A lane
+// only owns its ray, its closest hit so far and its vote on where to go next:
+//
+//   * a child is entered if ANY lane's ray enters its box (wave ballot); the child most
+//     lanes reach first is visited first, the other one is pushed;
+//   * every lane tests every primitive of a visited leaf; a lane whose ray does not reach the
+//     leaf's box simply finds no hit there;
+//   * an any-hit lane that has found its blocker sets its search bound to -inf, so all its
+//     further box and primitive tests fail, and the wave stops when no lane is left.
+//
+// This is exactly the per-lane traversal's result (closest hit is order independent, box
+// tests only cull); what changes is the cost.  Camera rays and shadow rays of neighbouring
+// samples touch nearly the same nodes (measured on the 1000x1000 bunny frame: a wave's union
+// is 15 nodes for camera rays against 12.6 for its longest lane, 24..30 against 18..23 for
+// shadow rays), so the packet executes about as many steps as its slowest lane did alone,
+// without the divergence, the per-lane stack traffic and 4 KiB of vector loads per step.
+// Incoherent rays (mirror bounces) keep the per-lane kernel.
+#pragma once
+
+#include "rt_core.h"
+
+// Uniform stack of one wave: `rows` dwords of LDS.  The top entry lives in a register (every
+// lane holds the same value), so a pop starts the LDS read of the entry below without waiting.
+struct WaveStack {
+    int32_t *base;
+    int32_t sp;
+    int32_t tos;  // same in all lanes
+    __device__ __forceinline__ void init(int32_t *b) { base = b; sp = 0; tos = RT_REF_NONE; }
+    __device__ __forceinline__ void push(int32_t ref) {
+        base[sp] = tos;  // all lanes store the same value to the same address
+        sp += 1;
+        tos = ref;
+    }
+    // Row 0 holds the RT_REF_NONE moved there by the first push; popping an empty stack
+    // returns RT_REF_NONE (end of traversal).
+    __device__ __forceinline__ int32_t pop() {
+        const int32_t r = __builtin_amdgcn_readfirstlane(tos);
+        sp = sp > 0 ? sp - 1 : 0;
+        tos = base[sp];
+        return r;
+    }
+};
+
+// Both child boxes of a wave-uniform node against this lane's ray (see fast_box2).
+__device__ __forceinline__ void packet_box2(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, const rt_f4 &c, float tmin,
+                                            float &el, float &er, bool &hl, bool &hr) {
+    fast_box2(s, a, b, c, tmin, el, er, hl, hr);
+}
+
+// Traverses the scene with the wave's 64 rays.  On entry `s` holds the lane's world-space ray,
+// search bound s.t (-inf for a lane without a ray), s.shape / s.tri = initial hit, and the
+// origin primitive.  Returns false on stack overflow.
+template <bool ANYHIT>
+__device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &s, float tmin, int32_t *lds_rows, int max_sp) {
+    const float ninf = -__builtin_inff();
+    const float wox = s.ox, woy = s.oy, woz = s.oz, wdx = s.dx, wdy = s.dy, wdz = s.dz;
+    WaveStack stk;
+    stk.init(lds_rows);
+    int32_t cur = S.tlas_root;
+    int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
+    for (;;) {
+        while (cur >= 0) {
+            const rt_f4 *n = S.nodes + (size_t)(uint32_t)cur * 4;
+            const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
+            const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
+            float el, er;
+            bool hl, hr;
+            packet_box2(s, a, b, c, tmin, el, er, hl, hr);
+            hr = hr && rref != RT_REF_NONE;
+            const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+            if (ml != 0ull && mr != 0ull) {
+                // lanes that reach the right child first (or reach only it) against those for the left
+                const unsigned long long right_first = __ballot(hr && (!hl || er < el));
+                const unsigned long long left_first = __ballot(hl && (!hr || el <= er));
+                const bool swap = __popcll(right_first) > __popcll(left_first);
+                if (stk.sp >= max_sp) return false;
+                stk.push(swap ? lref : rref);
+                cur = swap ? rref : lref;
+            } else if (ml != 0ull) {
+                cur = lref;
+            } else if (mr != 0ull) {
+                cur = rref;
+            } else {
+                cur = stk.pop();
+            }
+        }
+        if (cur == RT_REF_NONE) return true;
+        if (cur == RT_REF_EXIT_BLAS) {
+            fast_set_ray(s, wox, woy, woz, wdx, wdy, wdz);
+            cur_shape = -1;
+            cur = stk.pop();
+            continue;
+        }
+        const uint32_t v = (uint32_t)~cur;
+        const uint32_t cnt = v & 7u, first = v >> 3;
+        if (cur_shape >= 0) {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const int32_t gtri = (int32_t)(first + k);
+                const rt_f4 *tp = S.tri_xf + (size_t)(uint32_t)gtri * 3;
+                float t;
+                const bool own = cur_shape == s.org_shape && gtri == s.org_tri;
+                if (fast_triangle(s, tp[0], tp[1], tp[2], tmin, t) && !own) {
+                    s.shape = cur_shape;
+                    s.tri = gtri;
+                    s.t = ANYHIT ? ninf : t;
+                }
+            }
+            if (ANYHIT && __ballot(s.t > ninf) == 0ull) return true;
+            cur = stk.pop();
+            continue;
+        }
+        bool entered = false;
+        for (uint32_t k = 0; k < cnt && !entered; ++k) {
+            const rt_f4 *pp = S.tprims + (size_t)(first + k) * 4;
+            const rt_f4 h = pp[0];
+            const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
+                          proto_type = rt_as_int(h.w);
+            const bool is_inst = type == RT_SHAPE_INSTANCE;
+            if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
+                if (is_inst) {
+                    // enter the instance only if some lane's ray reaches its world box
+                    const rt_f4 f0 = pp[1], f1 = pp[2];
+                    float e;
+                    if (__ballot(fast_box(s, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e)) == 0ull) continue;
+                }
+                if (stk.sp + 2 > max_sp) return false;
+                if (k + 1 < cnt) stk.push(rt_make_leaf_ref(first + k + 1, cnt - k - 1));
+                stk.push(RT_REF_EXIT_BLAS);
+                if (is_inst) {
+                    const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
+                    const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
+                    fast_set_ray(s, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
+                                 ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
+                                 ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
+                                 (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
+                                 (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+                }
+                cur_shape = shape_id;
+                cur = blas_root;
+                entered = true;
+            } else {
+                // sphere / box / triangle at scene level, possibly instanced: the reference-shaped tests
+                RayF lr;
+                lr.ox = wox; lr.oy = woy; lr.oz = woz; lr.dx = wdx; lr.dy = wdy; lr.dz = wdz;
+                if (is_inst) ray_to_instance<false>(S, first + k, wox, woy, woz, wdx, wdy, wdz, lr);
+                else ray_finish<false>(lr);
+                float t;
+                if (payload_hit_f32(is_inst ? proto_type : type, pp[1], pp[2], pp[3], lr, tmin, s.t, t) &&
+                    shape_id != s.org_shape) {
+                    s.shape = shape_id;
+                    s.tri = -1;
+                    s.t = ANYHIT ? ninf : t;
+                }
+            }
+        }
+        if (entered) continue;
+        if (ANYHIT && __ballot(s.t > ninf) == 0ull) return true;
+        cur = stk.pop();
+    }
+}

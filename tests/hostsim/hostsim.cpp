@@ -12,6 +12,8 @@
 // fp32 arithmetic here is the host's (SSE, no contraction) and matches the
 // device's IEEE add/mul/div/sqrt; powf may differ in the last bits.
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -21,6 +23,9 @@
 struct Tally { unsigned long long node = 0, tri = 0, tprim = 0; };
 static thread_local Tally g_tally;
 #define RT_TALLY(what) (++g_tally.what)
+// optional record of every node / triangle index a ray touches (divergence studies)
+static thread_local std::vector<int32_t> *g_visit[2];
+#define RT_VISIT(kind, index) do { if (g_visit[kind]) g_visit[kind]->push_back((int32_t)(index)); } while (0)
 
 #include "../../include/rt_hip.h"
 #include "../../rust-raytracer_amd/csrc/bvh_build.h"
@@ -34,6 +39,11 @@ extern "C" void hostsim_record_work(uint16_t *primary_nodes, uint16_t *primary_t
     g_work_nodes[0] = primary_nodes; g_work_tris[0] = primary_tris;
     g_work_nodes[1] = shadow_nodes; g_work_tris[1] = shadow_tris;
 }
+
+namespace {
+struct VecStack;
+}
+extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args, int light, double *out);
 
 namespace {
 
@@ -62,6 +72,7 @@ std::string make_view(const RtScene &scene, HostScene &hs) {
     V.nodes = reinterpret_cast<const rt_f4 *>(hs.flat.nodes.data());
     V.tprims = reinterpret_cast<const rt_f4 *>(hs.flat.tprims.data());
     V.tris = reinterpret_cast<const rt_f4 *>(hs.flat.tris.data());
+    V.tri_xf = reinterpret_cast<const rt_f4 *>(hs.flat.tri_xf.data());
     V.tprim_xf = reinterpret_cast<const rt_f4 *>(hs.flat.tprim_xf.data());
     V.shapes = scene.shapes;
     V.protos = scene.protos;
@@ -349,4 +360,72 @@ extern "C" int64_t hostsim_bvh_dump(const RtScene *scene, int32_t which, int64_t
     *n_prims_out = (int64_t)t.order.size();
     if (stack_depth_out) *stack_depth_out = flat.stack_depth;
     return (int64_t)t.nodes.size();
+}
+
+// For every group of 64 consecutive rays (camera rays if light < 0, else the shadow rays of that
+// point light in lit order): the number of distinct nodes / triangles the group touches, against
+// the per-ray maxima.  out = {waves, sum union nodes, sum max-lane nodes, sum mean-lane nodes,
+// sum union tris, sum max-lane tris, sum mean-lane tris}.
+extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args, int light, double *out) {
+    HostScene hs;
+    if (!make_view(*scene, hs).empty()) return -1;
+    const RtSceneView &S = hs.view;
+    const uint32_t n = args->sqrt_rays_per_pixel, spp = n * n;
+    const uint32_t W = scene->image_width, H = scene->image_height;
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    std::vector<int32_t> tile_list;
+    for (uint32_t k = 0; k < tiles_x * tiles_y; ++k) tile_list.push_back((int32_t)k);
+    RtBatch B{};
+    B.tile_list = tile_list.data();
+    B.n_pixels = (uint32_t)tile_list.size() * tw * th;
+    B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x; B.width = W; B.height = H; B.n = n;
+    const long n_samples = (long)B.n_pixels * spp;
+    // rays: camera rays, or shadow rays from the camera rays' hit points
+    struct R { D3 o, d; float tmin, tmax; int32_t os, ot; bool anyhit; };
+    std::vector<R> rays;
+    VecStack stk; stk.v.assign((size_t)S.stack_depth + 2, 0);
+    for (long ls = 0; ls < n_samples; ++ls) {
+        uint32_t i, j;
+        if (!batch_pixel(B, (uint32_t)(ls / spp), i, j)) continue;
+        const uint32_t pq = (uint32_t)(ls % spp);
+        D3 o, d;
+        camera_ray(S.camera, i, j, pq / n, pq % n, n, o, d);
+        if (light < 0) { rays.push_back(R{o, d, 1.0f, INFINITY, -1, -1, false}); continue; }
+        FastTrav st; bool overflow = false;
+        fast_begin(S, st, stk, o, d, INFINITY, -1, -1, -1);
+        while (fast_step<VecStack, false>(S, st, stk, 1.0f, S.stack_depth, overflow)) {}
+        if (st.shape < 0) continue;
+        const int32_t st_ = S.shaders[S.shapes[st.shape].shader].type;
+        if (st_ != RT_SHADER_LAMBERTIAN && st_ != RT_SHADER_BLINN_PHONG) continue;
+        const D3 p = o + d * (double)st.t;
+        const D3 lp = d3(S.lights[S.point_lights[light]].position);
+        rays.push_back(R{p, lp - p, 1e-6f, 1.0f, st.shape, st.tri, true});
+    }
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<int32_t> vn, vt, un, ut;
+    for (size_t w0 = 0; w0 + 64 <= rays.size(); w0 += 64) {
+        un.clear(); ut.clear();
+        size_t maxn = 0, maxt = 0, sumn = 0, sumt = 0;
+        for (size_t l = 0; l < 64; ++l) {
+            const R &r = rays[w0 + l];
+            vn.clear(); vt.clear();
+            g_visit[0] = &vn; g_visit[1] = &vt;
+            FastTrav st; bool overflow = false;
+            fast_begin(S, st, stk, r.o, r.d, r.tmax, -1, r.os, r.ot);
+            if (r.anyhit) { while (fast_step<VecStack, true>(S, st, stk, r.tmin, S.stack_depth, overflow)) {} }
+            else { while (fast_step<VecStack, false>(S, st, stk, r.tmin, S.stack_depth, overflow)) {} }
+            g_visit[0] = g_visit[1] = nullptr;
+            maxn = std::max(maxn, vn.size()); maxt = std::max(maxt, vt.size());
+            sumn += vn.size(); sumt += vt.size();
+            un.insert(un.end(), vn.begin(), vn.end()); ut.insert(ut.end(), vt.begin(), vt.end());
+        }
+        // nodes of different instances of one mesh share indices; that is what a packet would share too
+        std::sort(un.begin(), un.end()); un.erase(std::unique(un.begin(), un.end()), un.end());
+        std::sort(ut.begin(), ut.end()); ut.erase(std::unique(ut.begin(), ut.end()), ut.end());
+        acc[0] += 1; acc[1] += (double)un.size(); acc[2] += (double)maxn; acc[3] += (double)sumn / 64.0;
+        acc[4] += (double)ut.size(); acc[5] += (double)maxt; acc[6] += (double)sumt / 64.0;
+    }
+    for (int k = 0; k < 7; ++k) out[k] = acc[k];
+    return 0;
 }
