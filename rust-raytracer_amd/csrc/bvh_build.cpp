@@ -53,6 +53,7 @@ struct Builder {
         TreeNode &n = tree.nodes[(size_t)me];
         n.left = l;
         n.right = r;
+        n.axis = axis;
         combine(tree.nodes[(size_t)l].bmin, tree.nodes[(size_t)l].bmax, tree.nodes[(size_t)r].bmin,
                 tree.nodes[(size_t)r].bmax, n.bmin, n.bmax);
         return me;
@@ -127,6 +128,7 @@ int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode
     const int32_t rref = emit(tree, n.right, prim_base, nodes);
     nodes[(size_t)me].left = lref;
     nodes[(size_t)me].right = rref;
+    nodes[(size_t)me].axis = n.axis;
     return me;
 }
 
@@ -137,8 +139,10 @@ int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNod
     nodes.emplace_back();
     RtNode rec{};
     set_child_box(rec, false, tree.nodes[0].bmin, tree.nodes[0].bmax);
-    rec.rmin_xy[0] = rec.rmin_xy[1] = rec.rz[0] = INFINITY;  // an empty box: nothing enters it
-    rec.rmax_xy[0] = rec.rmax_xy[1] = rec.rz[1] = -INFINITY;
+    // the absent right child is a box of zero extent: entry == exit on every axis, so no ray enters
+    // it under any form of the slab test (an inverted +-inf box would pass a min/max test)
+    rec.rmin_xy[0] = rec.rmin_xy[1] = rec.rz[0] = 0.0f;
+    rec.rmax_xy[0] = rec.rmax_xy[1] = rec.rz[1] = 0.0f;
     rec.right = RT_REF_NONE;
     nodes[(size_t)header] = rec;
     const int32_t root_ref = emit(tree, 0, prim_base, nodes);

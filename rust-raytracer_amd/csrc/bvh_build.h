@@ -20,6 +20,7 @@ struct TreeNode {
     double bmin[3], bmax[3];
     int32_t left = -1, right = -1;  // indices into Tree::nodes, -1 in a leaf
     uint32_t first = 0, count = 0;  // leaf: range of Tree::order
+    int32_t axis = 0;               // inner node: the axis its items were sorted on (0 x, 1 y, 2 z)
 };
 
 struct Tree {

@@ -688,6 +688,64 @@ RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &u, const rt_f4 &v, cons
     return true;
 }
 
+// One scene-level sphere / box / triangle payload (RtTPrim::f) against the ray held in `r`
+// (already in the primitive's space), fast-mode arithmetic: same acceptance rules as
+// sphere.rs:58-84, cuboid.rs:63-73 and triangle.rs:66-110, with the box decided by the culling
+// slab test (entry distance = the hit) and one reciprocal per primitive.
+RT_HD bool fast_payload_hit(const FastTrav &r, int32_t type, const rt_f4 &f0, const rt_f4 &f1, const rt_f4 &f2,
+                            float tmin, float &t_out) {
+    if (type == RT_SHAPE_SPHERE) {
+        const float ocx = r.ox - f0.x, ocy = r.oy - f0.y, ocz = r.oz - f0.z;
+        const float cd = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+        const float dd = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+        const float kx = ocy * r.dz - ocz * r.dy, ky = ocz * r.dx - ocx * r.dz, kz = ocx * r.dy - ocy * r.dx;
+        const float disc = dd * (f0.w * f0.w) - (kx * kx + ky * ky + kz * kz);  // see sphere_f32
+        if (!(disc >= 0.0f)) return false;
+        const float sq = __builtin_sqrtf(disc), inv = 1.0f / dd;
+        const float t1 = (-cd - sq) * inv, t2 = (-cd + sq) * inv;
+        const bool in1 = tmin <= t1 && t1 < r.t, in2 = tmin <= t2 && t2 < r.t;
+        t_out = in1 ? t1 : t2;  // t1 <= t2
+        return in1 || in2;
+    }
+    if (type == RT_SHAPE_BOX) return fast_box(r, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, t_out);
+    if (type == RT_SHAPE_TRIANGLE) {
+        const float abx = f0.w, aby = f1.x, abz = f1.y, acx = f1.z, acy = f1.w, acz = f2.x;
+        // c = ac x d ; det A = ab . c ; q = ab x ao ; see triangle_f32 for the determinants
+        const float cx = acy * r.dz - acz * r.dy, cy = acz * r.dx - acx * r.dz, cz = acx * r.dy - acy * r.dx;
+        const float det_a = abx * cx + aby * cy + abz * cz;
+        if (__builtin_fabsf(det_a) < 2.220446049250313e-16f) return false;
+        const float inv_det = 1.0f / det_a;
+        const float aox = f0.x - r.ox, aoy = f0.y - r.oy, aoz = f0.z - r.oz;
+        const float qx = aby * aoz - abz * aoy, qy = abz * aox - abx * aoz, qz = abx * aoy - aby * aox;
+        const float t = -(acx * qx + acy * qy + acz * qz) * inv_det;
+        if (!(t >= tmin && t <= r.t)) return false;
+        const float gamma = (r.dx * qx + r.dy * qy + r.dz * qz) * inv_det;
+        if (!(gamma >= 0.0f && gamma <= 1.0f)) return false;
+        const float beta = (aox * cx + aoy * cy + aoz * cz) * inv_det;
+        if (!(beta >= 0.0f && beta <= 1.0f - gamma)) return false;
+        t_out = t;
+        return true;
+    }
+    return false;
+}
+
+// The ray of `w` (world space) in the space of scene-level primitive `slot`: through the
+// instance's inverse transform (instance.rs:77-80) if it is one, unchanged otherwise.  The
+// search bound and origin primitive are carried over.
+RT_HD void fast_local_ray(const RtSceneView &S, uint32_t slot, bool is_inst, float wox, float woy, float woz, float wdx,
+                          float wdy, float wdz, const FastTrav &w, FastTrav &out) {
+    if (is_inst) {
+        const rt_f4 *m = S.tprim_xf + (size_t)slot * 3;
+        const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
+        fast_set_ray(out, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w, ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
+                     ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w, (r0.x * wdx + r0.y * wdy) + r0.z * wdz,
+                     (r1.x * wdx + r1.y * wdy) + r1.z * wdz, (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+    } else {
+        fast_set_ray(out, wox, woy, woz, wdx, wdy, wdz);
+    }
+    out.t = w.t;
+}
+
 // One outer iteration: walk inner nodes until a leaf (or the end), then process that leaf.
 // Returns false when the ray is finished (stack empty, any-hit satisfied, or overflow flagged).
 template <class Stack, bool ANYHIT>
@@ -775,13 +833,11 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
                     cur = blas_root;
                     entered = true;
                 } else if (shape_id != s.org_shape) {
-                    // sphere / box / triangle at scene level, possibly instanced: the reference-shaped tests
-                    RayF lr;
-                    lr.ox = s.ox; lr.oy = s.oy; lr.oz = s.oz; lr.dx = s.dx; lr.dy = s.dy; lr.dz = s.dz;
-                    if (is_inst) ray_to_instance<false>(S, first + k, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, lr);
-                    else ray_finish<false>(lr);
+                    // sphere / box / triangle at scene level, possibly instanced
+                    FastTrav lr;
+                    fast_local_ray(S, first + k, is_inst, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, s, lr);
                     float t;
-                    if (payload_hit_f32(is_inst ? proto_type : type, pp[1], pp[2], pp[3], lr, tmin, s.t, t)) {
+                    if (fast_payload_hit(lr, is_inst ? proto_type : type, pp[1], pp[2], pp[3], tmin, t)) {
                         s.t = t;
                         s.shape = shape_id;
                         s.tri = -1;

@@ -26,7 +26,8 @@ struct RtNode {
     float lz[2];  // left box min.z, max.z
     float rz[2];  // right box min.z, max.z
     int32_t left, right;
-    int32_t _pad[2];
+    int32_t axis;  // the axis the two children were split on: the left child holds the smaller centroids
+    int32_t _pad;
 };
 static_assert(sizeof(RtNode) == 64, "RtNode must be 64 bytes");
 

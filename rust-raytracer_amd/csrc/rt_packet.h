@@ -6,8 +6,9 @@
 // per lane through the vector memory pipeline, and every branch is a scalar branch.  A lane
 // only owns its ray, its closest hit so far and its vote on where to go next:
 //
-//   * a child is entered if ANY lane's ray enters its box (wave ballot); the child most
-//     lanes reach first is visited first, the other one is pushed;
+//   * a child is entered if ANY lane's ray enters its box (wave ballot); the child on the
+//     side most of the wave's rays come from (split axis of the node against the majority sign
+//     of the ray directions) is visited first, the other one is pushed;
 //   * every lane tests every primitive of a visited leaf; a lane whose ray does not reach the
 //     leaf's box simply finds no hit there;
 //   * an any-hit lane that has found its blocker sets its search bound to -inf, so all its
@@ -46,10 +47,15 @@ struct WaveStack {
     }
 };
 
-// Both child boxes of a wave-uniform node against this lane's ray (see fast_box2).
-__device__ __forceinline__ void packet_box2(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, const rt_f4 &c, float tmin,
-                                            float &el, float &er, bool &hl, bool &hr) {
-    fast_box2(s, a, b, c, tmin, el, er, hl, hr);
+// Bit k set if most of the wave's live rays run towards smaller coordinates along axis k: such a
+// wave reaches a node's RIGHT child first (the builder puts the smaller centroids left).
+__device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav &s, bool live) {
+    const int half = __popcll(__ballot(live)) >> 1;
+    uint32_t bits = 0;
+    if (__popcll(__ballot(live && s.dx < 0.0f)) > half) bits |= 1u;
+    if (__popcll(__ballot(live && s.dy < 0.0f)) > half) bits |= 2u;
+    if (__popcll(__ballot(live && s.dz < 0.0f)) > half) bits |= 4u;
+    return bits;
 }
 
 // Traverses the scene with the wave's 64 rays.  On entry `s` holds the lane's world-space ray,
@@ -59,6 +65,9 @@ template <bool ANYHIT>
 __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &s, float tmin, int32_t *lds_rows, int max_sp) {
     const float ninf = -__builtin_inff();
     const float wox = s.ox, woy = s.oy, woz = s.oz, wdx = s.dx, wdy = s.dy, wdz = s.dz;
+    const bool live = s.t > ninf;
+    const uint32_t world_bits = packet_direction_bits(s, live);
+    uint32_t dir_bits = world_bits;
     WaveStack stk;
     stk.init(lds_rows);
     int32_t cur = S.tlas_root;
@@ -67,24 +76,22 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
         while (cur >= 0) {
             const rt_f4 *n = S.nodes + (size_t)(uint32_t)cur * 4;
             const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
-            const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
             float el, er;
             bool hl, hr;
-            packet_box2(s, a, b, c, tmin, el, er, hl, hr);
-            hr = hr && rref != RT_REF_NONE;
+            fast_box2(s, a, b, c, tmin, el, er, hl, hr);  // a header's absent right child has an empty box
+            const bool right_first = ((dir_bits >> rt_as_int(l.z)) & 1u) != 0u;
+            const int32_t ref_l = rt_as_int(l.x), ref_r = rt_as_int(l.y);
+            const int32_t near = right_first ? ref_r : ref_l, far = right_first ? ref_l : ref_r;
             const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
-            if (ml != 0ull && mr != 0ull) {
-                // lanes that reach the right child first (or reach only it) against those for the left
-                const unsigned long long right_first = __ballot(hr && (!hl || er < el));
-                const unsigned long long left_first = __ballot(hl && (!hr || el <= er));
-                const bool swap = __popcll(right_first) > __popcll(left_first);
-                if (stk.sp >= max_sp) return false;
-                stk.push(swap ? lref : rref);
-                cur = swap ? rref : lref;
-            } else if (ml != 0ull) {
-                cur = lref;
-            } else if (mr != 0ull) {
-                cur = rref;
+            const bool any_near = (right_first ? mr : ml) != 0ull, any_far = (right_first ? ml : mr) != 0ull;
+            if (any_near) {
+                if (any_far) {
+                    if (stk.sp >= max_sp) return false;
+                    stk.push(far);
+                }
+                cur = near;
+            } else if (any_far) {
+                cur = far;
             } else {
                 cur = stk.pop();
             }
@@ -92,6 +99,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
         if (cur == RT_REF_NONE) return true;
         if (cur == RT_REF_EXIT_BLAS) {
             fast_set_ray(s, wox, woy, woz, wdx, wdy, wdz);
+            dir_bits = world_bits;
             cur_shape = -1;
             cur = stk.pop();
             continue;
@@ -139,19 +147,23 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
                                  ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
                                  (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
                                  (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+                    dir_bits = packet_direction_bits(s, live);
                 }
                 cur_shape = shape_id;
                 cur = blas_root;
                 entered = true;
             } else {
-                // sphere / box / triangle at scene level, possibly instanced: the reference-shaped tests
-                RayF lr;
-                lr.ox = wox; lr.oy = woy; lr.oz = woz; lr.dx = wdx; lr.dy = wdy; lr.dz = wdz;
-                if (is_inst) ray_to_instance<false>(S, first + k, wox, woy, woz, wdx, wdy, wdz, lr);
-                else ray_finish<false>(lr);
+                // sphere / box / triangle at scene level, possibly instanced
                 float t;
-                if (payload_hit_f32(is_inst ? proto_type : type, pp[1], pp[2], pp[3], lr, tmin, s.t, t) &&
-                    shape_id != s.org_shape) {
+                bool hit;
+                if (is_inst) {
+                    FastTrav lr;
+                    fast_local_ray(S, first + k, true, wox, woy, woz, wdx, wdy, wdz, s, lr);
+                    hit = fast_payload_hit(lr, proto_type, pp[1], pp[2], pp[3], tmin, t);
+                } else {
+                    hit = fast_payload_hit(s, type, pp[1], pp[2], pp[3], tmin, t);  // s holds the world ray here
+                }
+                if (hit && shape_id != s.org_shape) {
                     s.shape = shape_id;
                     s.tri = -1;
                     s.t = ANYHIT ? ninf : t;
