@@ -49,13 +49,16 @@ def algorithmic_bytes(workload):
         return None
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from a committed PMC profile, or None."""
+def measured_traffic(workload, kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
+    command (profiles/pmc_traffic.json, written by tools/summarize_pmc.py), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    want = {"trace_shadow": ("k_trace_packet<1>", "k_trace_fast<1>", "k_trace_shadow"),
+            "trace_closest": ("k_trace_packet<0>", "k_trace_fast<0>", "k_trace_closest")}.get(kernel_class, ())
     try:
         with open(path) as f:
             entry = json.load(f).get(workload)
-        return entry["bytes"] if entry else None
+        return entry["bytes"] if entry and entry.get("kernel", "").startswith(want) else None
     except Exception:
         return None
 
@@ -91,9 +94,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU implementation")
+    if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":  # rehearsal of the N > 1 path on a single GPU
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     rt = importlib.import_module("rust-raytracer_amd")
     gen = importlib.import_module("scenes.gen_scenes")
@@ -114,38 +122,87 @@ def main():
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
     tile_floats = tile * tile * 3
 
-    stream = torch.cuda.current_stream().cuda_stream
-    if world > 1:
-        part_buf = torch.zeros(stride * tile_floats, dtype=torch.float32, device="cuda")
-        gathered = torch.zeros(world * stride * tile_floats, dtype=torch.float32, device="cuda") if rank == 0 else None
-        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-    else:
-        part_buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
-        gathered, fb = None, part_buf
+    main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
+    staged = world > 1 and dist.get_backend() != "nccl"  # rehearsal on one GPU: gather through host memory (gloo)
 
-    def step(want_stats):
-        st = dev.render_device(rargs, part_buf.data_ptr(), stream=stream, want_stats=want_stats)
-        if world > 1:
-            dist.gather(part_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+    if world == 1:
+        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+
+        def step(want_stats):
+            return dev.render_device(rargs, fb.data_ptr(), stream=stream, want_stats=want_stats)
+
+        def drain():
+            pass
+    else:
+        # Two sets of buffers: while the gather of one frame is in flight the next frame renders.
+        part_floats = stride * tile_floats
+        part = [torch.zeros(part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros(world * part_floats, dtype=torch.float32, device="cuda") if rank == 0 else None
+                    for _ in range(2)]
+        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        side = torch.cuda.Stream()  # rank 0: waits for a gather and restores the image layout
+        pending = [None, None]      # the gather that last read part[b] / wrote gathered[b]
+        untiled = [None, None]      # event: gathered[b] has been consumed
+        counter = [0]
+
+        def step(want_stats):
+            b = counter[0] & 1
+            counter[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()  # stream-level: the gather of two frames ago has released part[b]
+            if untiled[b] is not None:
+                main_stream.wait_event(untiled[b])
+            st = dev.render_device(rargs, part[b].data_ptr(), stream=stream, want_stats=want_stats)
+            if staged:
+                host = part[b].cpu()
+                bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, bufs, dst=0)
+                if rank == 0:
+                    gathered[b].copy_(torch.cat(bufs))
+                    dev.untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=stream)
+                return st
+            pending[b] = dist.gather(part[b], list(gathered[b].chunk(world)) if rank == 0 else None, dst=0, async_op=True)
             if rank == 0:
-                dev.untile_device(rargs, gathered.data_ptr(), fb.data_ptr(), stream=stream)
-        return st
+                with torch.cuda.stream(side):
+                    pending[b].wait()
+                    dev.untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=side.cuda_stream)
+                    untiled[b] = side.record_event()
+            return st
+
+        def drain():
+            for w in pending:
+                if w is not None:
+                    w.wait()
+            main_stream.wait_stream(side)
 
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    # Ray counts and per-kernel device times come from the backend's own HIP events on the render
+    # stream.  On one GPU they are taken in every timed step (each step then waits for its frame);
+    # with several GPUs the timed steps are left free to overlap rendering with the gather, and the
+    # counts (identical for every frame) and kernel times are taken from the warm-up frames.
+    warm_stats = []
+    for _ in range(max(args.warmup, 1 if world > 1 else 0)):
+        warm_stats.append(step(world > 1))
     fence()
     t0 = time.perf_counter()
-    stats = [step(True) for _ in range(args.steps)]
+    stats = [step(world == 1) for _ in range(args.steps)]
     fence()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        frame_rays = warm_stats[-1].total_rays()
+        rays_local = float(frame_rays * args.steps)
+        stats = warm_stats
+    else:
+        rays_local = float(sum(s.total_rays() for s in stats))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([float(sum(s.total_rays() for s in stats))], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -155,6 +212,7 @@ def main():
     if rank == 0:
         value = total_rays / elapsed
         s0 = stats[0]
+        n_stat = len(stats)  # frames the kernel timings below were taken over
         # dominant kernel = the class with the most device time on this rank
         k_ms = [sum(s.kernel_ms[k] for s in stats) for k in range(rt.RT_K_COUNT)]
         k_n = [sum(s.kernel_launches[k] for s in stats) for k in range(rt.RT_K_COUNT)]
@@ -166,16 +224,16 @@ def main():
         if ab is not None and dom_name in ("trace_closest", "trace_shadow"):
             if dom_name == "trace_shadow":
                 bytes_per_step = s0.shadow_rays * ab["shadow"]["bytes_per_ray"]
-                launches_per_step = max(k_n[dom] // args.steps, 1)
+                launches_per_step = max(k_n[dom] // n_stat, 1)
             else:
                 bytes_per_step = (s0.primary_rays * ab["primary"]["bytes_per_ray"]
                                   + s0.secondary_rays * ab["secondary"]["bytes_per_ray"])
-                launches_per_step = max(k_n[dom] // args.steps, 1)
+                launches_per_step = max(k_n[dom] // n_stat, 1)
             # launches of one step share the step's rays; price the mean launch
             bytes_per_launch = bytes_per_step / launches_per_step
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, dom_name) if world == 1 else None,
                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms}
         out = {
             "metric": "rays/sec (all ray types), Stanford bunny 1000² spp9 d6, 1/2/4/8 GPUs",
@@ -192,9 +250,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "traversal": args.mode, "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
-                       "scene_upload_ms": upload_s * 1e3},
-            "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / args.steps for k in range(len(rt.KERNEL_CLASSES))},
-            "device_ms_per_step": sum(s.render_ms for s in stats) / args.steps,
+                       "scene_upload_ms": upload_s * 1e3,
+                       "kernel_times_from": "timed steps" if world == 1 else "warm-up steps (timed steps run unsynchronised)"},
+            "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / n_stat for k in range(len(rt.KERNEL_CLASSES))},
+            "device_ms_per_step": sum(s.render_ms for s in stats) / n_stat,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
