@@ -1,0 +1,162 @@
+// rt-cli -- command line front end over librt_hip.so with the reference CLI's flags
+// (raytracer-cli/src/main.rs:19-42), defaults (raytracer-lib/src/prelude.rs:51-59) and
+// call sequence (main.rs:51-104): read scene -> parse_scene -> render -> save.
+//
+//   rt-cli -i scene.json [-o out.png] [-x W] [-y H] [-r RPP] [-d DEPTH] [--aspect-ratio A]
+//          [--disable-shadows] [--render-normals] [--antialias-method normal|jittered|random]
+//          [--backend hip] [--device N] [--mode fast|reference] [--stats-json FILE]
+//
+// Only the HIP backend exists in this program; there is no CPU renderer to fall back to.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/rt_hip.h"
+
+namespace {
+
+int fail(const std::string &msg) {
+    std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    return 1;
+}
+
+int fail_rt(const char *what) {
+    std::fprintf(stderr, "Error: %s: %s\n", what, rt_last_error());
+    return 1;
+}
+
+void usage() {
+    std::fprintf(stderr,
+                 "Raytracer CLI (MI355X backend)\n\n"
+                 "Usage: rt-cli [OPTIONS] --scene-path <SCENE_PATH>\n\n"
+                 "Options:\n"
+                 "  -x, --width <WIDTH>\n  -y, --height <HEIGHT>\n  -i, --scene-path <SCENE_PATH>\n"
+                 "  -o, --output <OUTPUT_PATH>          [default: out.png]\n"
+                 "  -r, --rays-per-pixel <N>            a perfect square [default: 4]\n"
+                 "  -d, --recursion-depth <DEPTH>       [default: 3]\n"
+                 "      --aspect-ratio <ASPECT_RATIO>\n      --disable-shadows\n      --render-normals\n"
+                 "      --antialias-method <normal|jittered|random>\n"
+                 "      --backend <hip>                 [default: hip]\n"
+                 "      --device <ORDINAL>              [default: 0]\n"
+                 "      --mode <fast|reference>         traversal order [default: fast]\n"
+                 "      --stats-json <FILE>             ray counts and kernel times of the frame\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    RtParseArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.recursion_depth = -1;
+    std::string scene_path, output = "out.png", stats_json, backend = "hip";
+    long rays_per_pixel = 4;  // DEFAULT_RAYS_PER_PIXEL, prelude.rs:56
+    int aa = RT_AA_NORMAL, mode = RT_MODE_FAST, device = 0;
+
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "Error: a value is required for '%s'\n", name);
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "-x" || a == "--width") pa.image_width = (uint32_t)std::strtoul(value("--width"), nullptr, 10);
+        else if (a == "-y" || a == "--height") pa.image_height = (uint32_t)std::strtoul(value("--height"), nullptr, 10);
+        else if (a == "-i" || a == "--scene-path") scene_path = value("--scene-path");
+        else if (a == "-o" || a == "--output") output = value("--output");
+        else if (a == "-r" || a == "--rays-per-pixel") rays_per_pixel = std::strtol(value("--rays-per-pixel"), nullptr, 10);
+        else if (a == "-d" || a == "--recursion-depth") pa.recursion_depth = (int32_t)std::strtol(value("--recursion-depth"), nullptr, 10);
+        else if (a == "--aspect-ratio") pa.aspect_ratio = std::strtod(value("--aspect-ratio"), nullptr);
+        else if (a == "--disable-shadows") pa.disable_shadows = 1;
+        else if (a == "--render-normals") pa.render_normals = 1;
+        else if (a == "--antialias-method") {
+            const std::string v = value("--antialias-method");
+            if (v == "normal") aa = RT_AA_NORMAL;
+            else if (v == "jittered") aa = RT_AA_JITTERED;
+            else if (v == "random") aa = RT_AA_RANDOM;
+            else return fail("invalid value '" + v + "' for '--antialias-method'");
+        } else if (a == "--backend") backend = value("--backend");
+        else if (a == "--device") device = (int)std::strtol(value("--device"), nullptr, 10);
+        else if (a == "--mode") {
+            const std::string v = value("--mode");
+            if (v == "fast") mode = RT_MODE_FAST;
+            else if (v == "reference") mode = RT_MODE_REFERENCE_ORDER;
+            else return fail("invalid value '" + v + "' for '--mode'");
+        } else if (a == "--stats-json") stats_json = value("--stats-json");
+        else if (a == "-h" || a == "--help") {
+            usage();
+            return 0;
+        } else {
+            usage();
+            return fail("unexpected argument '" + a + "'");
+        }
+    }
+    if (scene_path.empty()) {
+        usage();
+        return fail("the following required arguments were not provided: --scene-path <SCENE_PATH>");
+    }
+    if (backend != "hip") return fail("backend '" + backend + "' is not part of this program (only 'hip' is)");
+
+    // main.rs:72-83: rays per pixel must be a perfect square
+    if (rays_per_pixel <= 0 || rays_per_pixel > 65535) return fail("rays_per_pixel must be a perfect square");
+    const long n = (long)std::sqrt((double)rays_per_pixel);
+    if (n * n != rays_per_pixel) return fail("rays_per_pixel must be a perfect square");
+
+    RtScene *scene = nullptr;
+    if (rt_parse_scene_file(scene_path.c_str(), &pa, &scene) != RT_OK) return fail_rt("scene");
+    RtBackend *be = nullptr;
+    if (rt_backend_create(device, &be) != RT_OK) {
+        rt_scene_destroy(scene);
+        return fail_rt("backend");
+    }
+    RtDeviceScene *ds = nullptr;
+    int rc = rt_scene_upload(be, scene, &ds);
+    if (rc != RT_OK) {
+        rt_backend_destroy(be);
+        rt_scene_destroy(scene);
+        return fail_rt("upload");
+    }
+    RtRenderArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.sqrt_rays_per_pixel = (uint16_t)n;
+    ra.antialias_method = aa;
+    ra.mode = mode;
+    const uint32_t W = scene->image_width, H = scene->image_height;
+    std::vector<float> fb((size_t)W * H * 3);
+    RtStats st;
+    rc = rt_render(be, ds, &ra, fb.data(), nullptr, &st);
+    int exit_code = 0;
+    if (rc != RT_OK) {
+        exit_code = fail_rt("render");
+    } else if (rt_save_png(output.c_str(), fb.data(), W, H) != RT_OK) {
+        exit_code = fail_rt("save");
+    } else {
+        const double rays = (double)(st.primary_rays + st.secondary_rays + st.shadow_rays);
+        std::fprintf(stderr, "Render complete: %ux%u, %ld rays per pixel, %.0f rays in %.3f ms (%.2f Grays/s)\n", W, H,
+                     rays_per_pixel, rays, st.render_ms, rays / (st.render_ms * 1e6));
+        if (!stats_json.empty()) {
+            FILE *f = std::fopen(stats_json.c_str(), "w");
+            if (!f) {
+                exit_code = fail("cannot open " + stats_json);
+            } else {
+                std::fprintf(f,
+                             "{\"width\": %u, \"height\": %u, \"rays_per_pixel\": %ld, \"primary_rays\": %llu, "
+                             "\"secondary_rays\": %llu, \"shadow_rays\": %llu, \"shaded_hits\": %llu, \"render_ms\": %.6f, "
+                             "\"kernel_ms\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f]}\n",
+                             W, H, rays_per_pixel, (unsigned long long)st.primary_rays,
+                             (unsigned long long)st.secondary_rays, (unsigned long long)st.shadow_rays,
+                             (unsigned long long)st.shaded_hits, st.render_ms, st.kernel_ms[0], st.kernel_ms[1],
+                             st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5]);
+                std::fclose(f);
+            }
+        }
+    }
+    rt_scene_free(ds);
+    rt_backend_destroy(be);
+    rt_scene_destroy(scene);
+    return exit_code;
+}

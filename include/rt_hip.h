@@ -201,6 +201,12 @@ int rt_trace_rays(RtBackend *backend, const RtDeviceScene *dev_scene, uint64_t n
  * `rgb8_out` holds width*height*3 bytes. */
 int rt_framebuffer_to_rgb8(const float *fb_rgb, uint32_t width, uint32_t height, uint8_t *rgb8_out);
 
+/* output::save -- raytracer-cli/src/output/mod.rs:7-17 with save_to_png
+ * (png_export.rs:1-14): writes the framebuffer as an 8-bit RGB PNG.  A path whose
+ * extension is not "png" is RT_ERR_UNSUPPORTED (the reference panics with
+ * unimplemented!); a path without extension writes nothing, as there. */
+int rt_save_png(const char *path, const float *fb_rgb, uint32_t width, uint32_t height);
+
 /* Number of point lights of an uploaded scene (the stride of RtRayIds.shadow_*). */
 uint32_t rt_scene_point_light_count(const RtDeviceScene *dev_scene);
 

@@ -228,6 +228,7 @@ def lib() -> C.CDLL:
                                      C.POINTER(C.c_uint32)]
     L.rt_untile_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, vp, vp]
     L.rt_framebuffer_to_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.rt_save_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.rt_scene_point_light_count.argtypes = [vp]
     L.rt_scene_point_light_count.restype = C.c_uint32
     _lib = L
@@ -509,8 +510,5 @@ def render(scene: Scene, sqrt_rays_per_pixel: int, antialias_method=AntialiasMet
 
 def save_png(path: str, fb: Framebuffer) -> None:
     """output::save -- raytracer-cli/src/output/mod.rs:7-17 (only .png is supported there too)."""
-    if not path.lower().endswith(".png"):
-        raise RtError(RT_ERR_UNSUPPORTED, "Unsupported file format")
-    from PIL import Image
-
-    Image.fromarray(fb.to_rgb8(), "RGB").save(path)
+    src = np.ascontiguousarray(fb.pixels, np.float32)
+    _check(lib().rt_save_png(path.encode(), src.ctypes.data, fb.width, fb.height))
