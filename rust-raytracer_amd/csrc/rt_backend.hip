@@ -28,6 +28,7 @@
 #endif
 #define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
 #define RT_PACKET_BLOCK 64
+#define RT_LIT_BLOCK 1024
 
 namespace {
 
@@ -175,11 +176,12 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
 }
 
 // ---- compaction of the lit table into a list of sample indices, in sample order
-// (count per 256-sample block -> exclusive scan of the block counts -> scatter).
+// (count per 1024-sample block -> exclusive scan of the block counts -> scatter).  Large blocks
+// keep the single-block scan in the middle short: it is pure latency on the frame's critical path.
 // No global atomics: thousands of waves adding to one counter serialise on it.
 
-__global__ void __launch_bounds__(RT_BLOCK) k_lit_count(RtBuffers Q, uint32_t n_samples) {
-    const uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+__global__ void __launch_bounds__(RT_LIT_BLOCK) k_lit_count(RtBuffers Q, uint32_t n_samples) {
+    const uint32_t s = blockIdx.x * RT_LIT_BLOCK + threadIdx.x;
     const int n = __syncthreads_count(s < n_samples && Q.l_shape[s] >= 0 ? 1 : 0);
     if (threadIdx.x == 0) Q.block_counts[blockIdx.x] = (uint32_t)n;
 }
@@ -208,9 +210,9 @@ __global__ void __launch_bounds__(1024) k_lit_scan(RtBuffers Q, uint32_t n_block
     if (threadIdx.x == 1023) Q.counters[RT_CNT_LIT] = part[1023];
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
-    __shared__ uint32_t wave_total[RT_BLOCK / 64];
-    const uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+__global__ void __launch_bounds__(RT_LIT_BLOCK) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
+    __shared__ uint32_t wave_total[RT_LIT_BLOCK / 64];
+    const uint32_t s = blockIdx.x * RT_LIT_BLOCK + threadIdx.x;
     const bool lit = s < n_samples && Q.l_shape[s] >= 0;
     const unsigned long long mask = __ballot(lit);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -581,9 +583,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         }
         if (ds->has_lit) {
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_lit_count, dim3(full_grid), dim3(RT_BLOCK), 0, stream, Q, n_samples);
-            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(1024), 0, stream, Q, full_grid);
-            hipLaunchKernelGGL(k_lit_scatter, dim3(full_grid), dim3(RT_BLOCK), 0, stream, Q, n_samples);
+            const uint32_t lit_grid = (n_samples + RT_LIT_BLOCK - 1) / RT_LIT_BLOCK;
+            hipLaunchKernelGGL(k_lit_count, dim3(lit_grid), dim3(RT_LIT_BLOCK), 0, stream, Q, n_samples);
+            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(1024), 0, stream, Q, lit_grid);
+            hipLaunchKernelGGL(k_lit_scatter, dim3(lit_grid), dim3(RT_LIT_BLOCK), 0, stream, Q, n_samples);
             tm.end();
             // the number of lit hits is only known on the device: size the grids for the worst
             // case, surplus blocks return at once
