@@ -149,7 +149,7 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
     if (live) {
         if (KIND == 1) {
             sample = Q.lit_list[idx];
-            live = shadow_setup<true>(S, Q, blockIdx.y, sample, r);
+            live = shadow_setup_lit(S, Q, blockIdx.y, sample, r);
         } else {
             live = closest_setup(S, Q, B, 0, idx, r);
         }

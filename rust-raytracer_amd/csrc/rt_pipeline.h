@@ -328,6 +328,24 @@ RT_HD bool shadow_setup(const RtSceneView &S, const RtBuffers &Q, uint32_t light
     return true;
 }
 
+// The same for an entry of the lit list (whose samples all hold a lit hit): every field is
+// fetched before any is looked at, so the loads are in flight together instead of one
+// round trip to memory after the other.
+RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample, RaySetup &r) {
+    const size_t k = (size_t)light_slot * Q.capacity + sample;
+    const int32_t org_shape = Q.l_shape[sample], org_tri = Q.l_tri[sample], shape0 = Q.occ_shape[k];
+    const float t0 = Q.occ_t[k];
+    const double px = Q.l_p[0][sample], py = Q.l_p[1][sample], pz = Q.l_p[2][sample];
+    const RtLight &light = S.lights[S.point_lights[light_slot]];
+    r.org_shape = org_shape;
+    r.org_tri = org_tri;
+    r.t0 = t0;
+    r.shape0 = shape0;
+    r.o = D3{px, py, pz};
+    r.d = d3(light.position) - r.o;
+    return org_shape >= 0 && shape0 < 0;
+}
+
 RT_HD void shadow_store(const RtBuffers &Q, uint32_t light_slot, uint32_t sample, int32_t shape, int32_t tri) {
     const size_t k = (size_t)light_slot * Q.capacity + sample;
     Q.occ_shape[k] = shape;
