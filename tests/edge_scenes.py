@@ -1,0 +1,66 @@
+"""Small hand-written scenes for corner cases of the render path (shared by the CPU and GPU parity tests).
+Each entry: name -> (scene dict, width, height, sqrt_rpp)."""
+import json
+import os
+
+CAM = [{"_name": "main", "_type": "perspective", "position": "0.013 0.021 6", "viewDir": "0.002 -0.003 -1", "focalLength": 1.0}]
+SHADERS = [
+    {"_name": "lam", "_type": "Lambertian", "diffuse": "0.7 0.3 0.2"},
+    {"_name": "bp", "_type": "BlinnPhong", "diffuse": "0.2 0.5 0.7", "specular": "1 1 1", "phongExp": 24.0},
+    {"_name": "mir", "_type": "Mirror"},
+]
+POINT = {"_type": "point", "position": "3.1 4.3 5.2", "intensity": "1 1 1"}
+AMBIENT = {"_type": "ambient", "intensity": "0.15 0.15 0.2"}
+BALLS = [
+    {"_name": "a", "_type": "sphere", "shader": "lam", "center": "-1.1 0 0", "radius": 1.0},
+    {"_name": "b", "_type": "sphere", "shader": "bp", "center": "1.2 0.1 -0.5", "radius": 0.8},
+    {"_name": "floor", "_type": "box", "shader": "lam", "minPt": "-6 -1.5 -6", "maxPt": "6 -1.0 6"},
+]
+
+
+def _scene(**kw):
+    s = {"camera": CAM, "shader": SHADERS}
+    s.update(kw)
+    return {"scene": s}
+
+
+def degenerate_obj(path):
+    """A quad of two triangles, one zero-area triangle (the reference never hits it: det A == 0) and a sliver."""
+    with open(path, "w") as f:
+        f.write("o m\nv -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nv 0.5 0.5 0.5\nv 0.5 0.5 0.5\nv 0.25 0.25 0.5\n"
+                "v -0.5 0.9 0.4\nv 0.5 0.9000001 0.4\nv 0 0.9 0.45\n"
+                "f 1 2 3\nf 1 3 4\nf 5 6 7\nf 8 9 10\n")
+
+
+def scenes(tmp_dir):
+    obj = os.path.join(tmp_dir, "degenerate.obj")
+    degenerate_obj(obj)
+    out = {
+        "no_lights": (_scene(shape=BALLS), 64, 48, 2),
+        "ambient_only": (_scene(shape=BALLS, light=[AMBIENT]), 64, 48, 2),
+        "one_shape": (_scene(shape=BALLS[:1], light=[POINT]), 48, 48, 1),
+        "one_pixel": (_scene(shape=BALLS, light=[POINT, AMBIENT]), 1, 1, 3),
+        "wide_aspect": (_scene(shape=BALLS, light=[POINT]), 150, 20, 2),
+        "odd_size_many_samples": (_scene(shape=BALLS, light=[POINT, AMBIENT]), 37, 23, 5),
+        "camera_inside_box": (_scene(shape=BALLS + [{"_name": "room", "_type": "box", "shader": "bp", "minPt": "-8 -8 -8",
+                                                     "maxPt": "8 8 8"}], light=[POINT]), 64, 48, 2),
+        "mirror_pair": (_scene(shape=[{"_name": "m1", "_type": "sphere", "shader": "mir", "center": "-1.05 0 0", "radius": 1.0},
+                                      {"_name": "m2", "_type": "sphere", "shader": "mir", "center": "1.05 0 0", "radius": 1.0},
+                                      BALLS[2]], light=[POINT]), 80, 60, 2),
+        "degenerate_mesh": (_scene(shape=[{"_name": "mesh", "_type": "mesh", "shader": "bp", "file": "degenerate.obj"}, BALLS[2]],
+                                   light=[POINT, AMBIENT]), 96, 72, 2),
+        "scaled_instances": (_scene(
+            instance=[{"_name": "proto", "_type": "mesh", "shader": "lam", "file": "degenerate.obj"},
+                      {"_name": "ball", "_type": "sphere", "shader": "lam", "center": "0 0 0", "radius": 1.0}],
+            shape=[{"_name": "i1", "_type": "instance", "shader": "bp", "_id": "proto",
+                    "xform": [{"type": "scale", "amount": "1.5 0.7 1"}, {"type": "rotate", "axis": "Y", "amount": 35},
+                              {"type": "translate", "amount": "-0.8 0 0"}]},
+                   {"_name": "i2", "_type": "instance", "shader": "lam", "_id": "ball",
+                    "xform": [{"type": "scale", "amount": "0.4 1.3 0.6"}, {"type": "translate", "amount": "1.4 0 0.5"}]},
+                   BALLS[2]], light=[POINT]), 96, 72, 2),
+    }
+    return {k: (json.dumps(v[0]), tmp_dir) + v[1:] for k, v in out.items()}
+
+
+NAMES = ["no_lights", "ambient_only", "one_shape", "one_pixel", "wide_aspect", "odd_size_many_samples", "camera_inside_box",
+         "mirror_pair", "degenerate_mesh", "scaled_instances"]

@@ -193,3 +193,24 @@ def test_drop_in_render_function(rt, scene_path):
     assert parity.image_metrics(fb.pixels, ref_fb)["max_abs_diff"] <= 1
     assert fb.width == 64 and fb.height == 48 and calls == [1]
     assert fb.get_pixel(0, 47).tolist() == pytest.approx([0.198] * 3)
+
+
+import edge_scenes
+
+
+@pytest.mark.parametrize("name", edge_scenes.NAMES)
+def test_corner_case_scenes(rt, backend, tmp_path, name):
+    """No lights, ambient only, one pixel, odd sizes (partly filled waves), camera inside a box, facing
+    mirrors, a mesh with a zero-area triangle, non-uniformly scaled instances."""
+    text, data_dir, w, h, n = edge_scenes.scenes(str(tmp_path))[name]
+    sc = rt.parse_scene(text, data_dir, image_width=w, image_height=h, recursion_depth=5)
+    dev = backend.upload(sc)
+    fb_o, ids_o, cnt = oracle_lib.render(sc, n)
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        fb, ids, stats = dev.render(n, mode=mode, want_ids=True)
+        assert np.array_equal(ids.primary_shape, ids_o.primary_shape) and np.array_equal(ids.primary_tri, ids_o.primary_tri)
+        assert np.array_equal(ids.final_shape, ids_o.final_shape) and np.array_equal(ids.bounces, ids_o.bounces)
+        assert np.array_equal(ids.shadow_shape >= 0, ids_o.shadow_shape >= 0)
+        assert parity.image_metrics(fb.pixels, fb_o)["max_abs_diff"] <= 1
+        assert stats.total_rays() == sum(cnt["rays"])
+    dev.close()

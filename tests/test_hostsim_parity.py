@@ -103,3 +103,23 @@ def test_trace_rays_matches_oracle(rt, scene_path):
         assert agree >= 0.9999, agree
         both = (s == s_o) & (s >= 0)
         assert np.allclose(t[both], t_o[both], rtol=2e-5)
+
+
+import edge_scenes
+
+
+@pytest.mark.parametrize("name", edge_scenes.NAMES)
+def test_corner_case_scenes(rt, tmp_path, name):
+    """No lights, ambient only, one pixel, odd sizes, camera inside a box, facing mirrors, a mesh with
+    a zero-area triangle, non-uniformly scaled instances."""
+    text, data_dir, w, h, n = edge_scenes.scenes(str(tmp_path))[name]
+    sc = rt.parse_scene(text, data_dir, image_width=w, image_height=h, recursion_depth=5)
+    fb_o, ids_o, cnt = O.render(sc, n)
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        fb, ids, stats = HS.render(sc, n, mode=mode)
+        # tiny frames: compare exactly (a single differing sample would already break the fraction bars)
+        assert np.array_equal(ids.primary_shape, ids_o.primary_shape) and np.array_equal(ids.primary_tri, ids_o.primary_tri)
+        assert np.array_equal(ids.final_shape, ids_o.final_shape) and np.array_equal(ids.bounces, ids_o.bounces)
+        assert np.array_equal(ids.shadow_shape >= 0, ids_o.shadow_shape >= 0)
+        assert parity.image_metrics(fb, fb_o)["max_abs_diff"] <= 1
+        assert stats.total_rays() == sum(cnt["rays"])
