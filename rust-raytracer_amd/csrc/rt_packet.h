@@ -70,6 +70,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
     uint32_t dir_bits = world_bits;
     WaveStack stk;
     stk.init(lds_rows);
+    bool overflow = false;  // cannot happen with the host's sizing of the stack; kept from writing outside the rows
     int32_t cur = S.tlas_root;
     int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
     for (;;) {
@@ -86,7 +87,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
             const bool any_near = (right_first ? mr : ml) != 0ull, any_far = (right_first ? ml : mr) != 0ull;
             if (any_near) {
                 if (any_far) {
-                    if (stk.sp >= max_sp) return false;
+                    overflow = overflow || stk.sp >= max_sp;
+                    stk.sp = stk.sp >= max_sp ? max_sp - 1 : stk.sp;
                     stk.push(far);
                 }
                 cur = near;
@@ -96,7 +98,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
                 cur = stk.pop();
             }
         }
-        if (cur == RT_REF_NONE) return true;
+        if (cur == RT_REF_NONE) break;
         if (cur == RT_REF_EXIT_BLAS) {
             fast_set_ray(s, wox, woy, woz, wdx, wdy, wdz);
             dir_bits = world_bits;
@@ -118,8 +120,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
                     s.t = ANYHIT ? ninf : t;
                 }
             }
-            if (ANYHIT && __ballot(s.t > ninf) == 0ull) return true;
-            cur = stk.pop();
+            cur = (ANYHIT && __ballot(s.t > ninf) == 0ull) ? RT_REF_NONE : stk.pop();
             continue;
         }
         bool entered = false;
@@ -136,7 +137,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
                     float e;
                     if (__ballot(fast_box(s, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e)) == 0ull) continue;
                 }
-                if (stk.sp + 2 > max_sp) return false;
+                overflow = overflow || stk.sp + 2 > max_sp;
+                stk.sp = stk.sp + 2 > max_sp ? max_sp - 2 : stk.sp;
                 if (k + 1 < cnt) stk.push(rt_make_leaf_ref(first + k + 1, cnt - k - 1));
                 stk.push(RT_REF_EXIT_BLAS);
                 if (is_inst) {
@@ -171,7 +173,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
             }
         }
         if (entered) continue;
-        if (ANYHIT && __ballot(s.t > ninf) == 0ull) return true;
-        cur = stk.pop();
+        cur = (ANYHIT && __ballot(s.t > ninf) == 0ull) ? RT_REF_NONE : stk.pop();
     }
+    return !overflow;
 }
