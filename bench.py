@@ -122,8 +122,12 @@ def main():
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
     tile_floats = tile * tile * 3
 
-    main_stream = torch.cuda.current_stream()
+    # A stream of our own: the backend treats a null stream handle as "use the backend's private
+    # stream", which would not be ordered with torch's copies and collectives.
+    main_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(main_stream)
     stream = main_stream.cuda_stream
+    assert stream != 0
     staged = world > 1 and dist.get_backend() != "nccl"  # rehearsal on one GPU: gather through host memory (gloo)
 
     if world == 1:
@@ -201,6 +205,17 @@ def main():
     else:
         rays_local = float(sum(s.total_rays() for s in stats))
 
+    # Outside the timed region: the gathered frame must be bit-identical with the same frame rendered
+    # whole on rank 0 (static tile map, ordered per-pixel sums).
+    frame_check = None
+    if world > 1 and rank == 0:
+        whole = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile)), whole.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        if not torch.equal(whole, fb):
+            raise SystemExit(f"gathered frame differs from the single-GPU frame in {int((whole != fb).sum())} values")
+        frame_check = "gathered frame bit-identical with rank 0's single-GPU render"
+
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -256,6 +271,8 @@ def main():
             "device_ms_per_step": sum(s.render_ms for s in stats) / n_stat,
             "roofline": roofline,
         }
+        if frame_check:
+            out["config"]["frame_check"] = frame_check
         if world == 1 and not args.no_cpu_baseline:
             sample_px = 700 if args.workload.startswith("bunny") else 500
             v1, dt1 = cpu_baseline(rt, scene_name, depth, sample_px, 3, 1)
