@@ -160,7 +160,9 @@ int rt_render(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRender
 
 /* Same, but `fb_rgb_dev` and the `ids_dev` arrays are DEVICE pointers and the
  * work is enqueued on `hip_stream` (a hipStream_t, NULL = the backend's own
- * stream).  Returns after enqueueing when stats_out is NULL; with stats_out it
+ * stream, which is created non-blocking: work on it is NOT ordered with the
+ * caller's null-stream work, so pass the stream that produces / consumes the
+ * buffers).  Returns after enqueueing when stats_out is NULL; with stats_out it
  * waits for the stream and fills the counters and timings. */
 int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
                      float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream,
