@@ -186,24 +186,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Ray counts and per-kernel device times come from the backend's own HIP events on the render
-    # stream.  On one GPU they are taken in every timed step (each step then waits for its frame);
-    # with several GPUs the timed steps are left free to overlap rendering with the gather, and the
-    # counts (identical for every frame) and kernel times are taken from the warm-up frames.
-    warm_stats = []
-    for _ in range(max(args.warmup, 1 if world > 1 else 0)):
-        warm_stats.append(step(world > 1))
+    # Warm-up frames are rendered with the backend's full statistics (an event pair around every
+    # kernel, counters read back, the host waits for each frame): they give the ray counts, which
+    # are the same for every frame, and the split of a frame over the kernel classes.  The timed
+    # frames are enqueued back to back without waiting; only the dominant kernel class carries an
+    # event pair there (its durations are collected after the loop for the roofline), because
+    # every pair drains the pipeline for a few microseconds.
+    warm_stats = [step(True) for _ in range(max(args.warmup, 1))]
     fence()
+    k_warm = [warm_stats[-1].kernel_ms[k] for k in range(rt.RT_K_COUNT)]
+    dom = max(range(len(rt.KERNEL_CLASSES)), key=lambda k: k_warm[k])
+    rargs.timed_classes = 1 << dom
     t0 = time.perf_counter()
-    stats = [step(world == 1) for _ in range(args.steps)]
+    for _ in range(args.steps):
+        step(False)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        frame_rays = warm_stats[-1].total_rays()
-        rays_local = float(frame_rays * args.steps)
-        stats = warm_stats
-    else:
-        rays_local = float(sum(s.total_rays() for s in stats))
+    timed = backend.collect_timings()
+    rargs.timed_classes = 0
+    stats = warm_stats[-1:]  # the last warm-up frame: caches and clocks have settled
+    rays_local = float(warm_stats[-1].total_rays() * args.steps)
 
     # Outside the timed region: the gathered frame must be bit-identical with the same frame rendered
     # whole on rank 0 (static tile map, ordered per-pixel sums).
@@ -228,12 +230,12 @@ def main():
         value = total_rays / elapsed
         s0 = stats[0]
         n_stat = len(stats)  # frames the kernel timings below were taken over
-        # dominant kernel = the class with the most device time on this rank
+        # dominant kernel = the class with the most device time on this rank (warm-up frames);
+        # its launch duration is the one measured in the timed frames
         k_ms = [sum(s.kernel_ms[k] for s in stats) for k in range(rt.RT_K_COUNT)]
         k_n = [sum(s.kernel_launches[k] for s in stats) for k in range(rt.RT_K_COUNT)]
-        dom = max(range(len(rt.KERNEL_CLASSES)), key=lambda k: k_ms[k])
         dom_name = rt.KERNEL_CLASSES[dom]
-        avg_ms = k_ms[dom] / max(k_n[dom], 1)
+        avg_ms = timed.kernel_ms[dom] / max(timed.kernel_launches[dom], 1)
         ab = algorithmic_bytes(args.workload)
         roofline = None
         if ab is not None and dom_name in ("trace_closest", "trace_shadow"):
@@ -249,7 +251,8 @@ def main():
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, dom_name) if world == 1 else None,
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms}
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                        "launches_timed": int(timed.kernel_launches[dom])}
         out = {
             "metric": "rays/sec (all ray types), Stanford bunny 1000² spp9 d6, 1/2/4/8 GPUs",
             "value": value,
@@ -266,7 +269,7 @@ def main():
             "config": {"workload": desc, "traversal": args.mode, "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
                        "scene_upload_ms": upload_s * 1e3,
-                       "kernel_times_from": "timed steps" if world == 1 else "warm-up steps (timed steps run unsynchronised)"},
+                       "kernel_split_from": "warm-up frames (fully instrumented); roofline duration from the timed frames"},
             "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / n_stat for k in range(len(rt.KERNEL_CLASSES))},
             "device_ms_per_step": sum(s.render_ms for s in stats) / n_stat,
             "roofline": roofline,

@@ -100,7 +100,10 @@ enum { RT_MODE_FAST = 0, RT_MODE_REFERENCE_ORDER = 1 };
 
 typedef struct RtRenderArgs {
     uint16_t sqrt_rays_per_pixel; /* render.rs:9 */
-    uint16_t _pad0;
+    /* Bit k set: time the kernels of class RT_K_<k> of this frame with HIP events WITHOUT waiting
+     * for them; rt_collect_timings adds them up later.  Only looked at when the call is given no
+     * stats_out (which times every class and waits).  0 = no events at all. */
+    uint16_t timed_classes;
     int32_t antialias_method;     /* render.rs:10 */
     int32_t mode;                 /* RT_MODE_* */
     /* Image partition for multi-GPU rendering.  The image is cut into
@@ -167,6 +170,13 @@ int rt_render(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRender
 int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
                      float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream,
                      RtStats *stats_out);
+
+/* Waits for the frames enqueued with RtRenderArgs::timed_classes since the last call and fills
+ * kernel_ms / kernel_launches of `out` with their sums (all other fields 0).  Lets a caller keep
+ * many frames in flight and still learn how long a kernel took on the device: every event pair
+ * costs a few microseconds of pipeline drain, so timing one class disturbs a frame far less than
+ * stats_out does. */
+int rt_collect_timings(RtBackend *backend, RtStats *out);
 
 /* Tile bookkeeping of a partitioned render (no counterpart in the reference, which has
  * one thread and one image): how many tiles the image has, how many belong to

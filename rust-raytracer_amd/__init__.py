@@ -156,7 +156,7 @@ class RtParseArgs(C.Structure):
 class RtRenderArgs(C.Structure):
     _fields_ = [
         ("sqrt_rays_per_pixel", C.c_uint16),
-        ("_pad0", C.c_uint16),
+        ("timed_classes", C.c_uint16),
         ("antialias_method", C.c_int32),
         ("mode", C.c_int32),
         ("tile_w", C.c_uint32),
@@ -221,6 +221,7 @@ def lib() -> C.CDLL:
     L.rt_scene_free.restype = None
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), C.POINTER(RtStats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp, C.POINTER(RtStats)]
+    L.rt_collect_timings.argtypes = [vp, C.POINTER(RtStats)]
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
     L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -376,6 +377,12 @@ class Backend:
     @property
     def handle(self):
         return self._h
+
+    def collect_timings(self) -> RtStats:
+        """rt_collect_timings: device times of the frames enqueued with RtRenderArgs.timed_classes."""
+        st = RtStats()
+        _check(lib().rt_collect_timings(self._h, C.byref(st)))
+        return st
 
     def upload(self, scene: Scene) -> "DeviceScene":
         h = C.c_void_p()

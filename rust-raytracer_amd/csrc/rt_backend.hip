@@ -325,9 +325,17 @@ int dev_upload(const std::vector<T> &v, T **out) {
 
 }  // namespace
 
+struct RtEventPair {
+    hipEvent_t a, b;
+    int klass;
+};
+
 struct RtBackend {
     int device = 0;
     hipStream_t stream = nullptr;
+    // event pairs of frames enqueued with RtRenderArgs::timed_classes, until rt_collect_timings
+    std::vector<RtEventPair> deferred;
+    hipStream_t deferred_stream = nullptr;
     // batch buffers, grown on demand
     RtBuffers buf{};
     std::vector<void *> buf_allocs;
@@ -430,17 +438,17 @@ void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t par
         }
 }
 
-struct EventPair {
-    hipEvent_t a, b;
-    int klass;
-};
+typedef RtEventPair EventPair;
 
 struct Timing {
     bool on = false;
+    uint32_t mask = ~0u;  // kernel classes to time
+    bool open = false;
     std::vector<EventPair> pairs;
     hipStream_t stream = nullptr;
     int begin(int klass) {
-        if (!on) return 0;
+        open = on && ((mask >> klass) & 1u) != 0u;
+        if (!open) return 0;
         EventPair p;
         p.klass = klass;
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
@@ -449,7 +457,8 @@ struct Timing {
         return 0;
     }
     void end() {
-        if (on) (void)hipEventRecord(pairs.back().b, stream);
+        if (open) (void)hipEventRecord(pairs.back().b, stream);
+        open = false;
     }
     void collect(RtStats *st) {
         for (auto &p : pairs) {
@@ -530,7 +539,8 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     }
 
     Timing tm;
-    tm.on = stats != nullptr;
+    tm.on = stats != nullptr || args->timed_classes != 0;
+    if (!stats) tm.mask = args->timed_classes;
     tm.stream = stream;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
@@ -619,6 +629,11 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         }
     }
     RT_HIP(hipGetLastError());
+    if (!stats && !tm.pairs.empty()) {  // read later by rt_collect_timings
+        be->deferred.insert(be->deferred.end(), tm.pairs.begin(), tm.pairs.end());
+        be->deferred_stream = stream;
+        tm.pairs.clear();
+    }
     if (stats) {
         RT_HIP(hipEventRecord(ev1, stream));
         RT_HIP(hipStreamSynchronize(stream));
@@ -676,6 +691,10 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
     if (!be) return;
     (void)hipSetDevice(be->device);
     if (be->stream) (void)hipStreamSynchronize(be->stream);
+    for (auto &p : be->deferred) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
     free_all(be->buf_allocs);
     if (be->tile_list) (void)hipFree(be->tile_list);
     if (be->tile_where) (void)hipFree(be->tile_where);
@@ -760,6 +779,25 @@ extern "C" void rt_scene_free(RtDeviceScene *ds) {
     (void)hipDeviceSynchronize();
     free_all(ds->allocs);
     delete ds;
+}
+
+extern "C" int rt_collect_timings(RtBackend *be, RtStats *out) {
+    if (!be || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    if (be->deferred.empty()) return RT_OK;
+    RT_HIP(hipSetDevice(be->device));
+    RT_HIP(hipStreamSynchronize(be->deferred_stream));
+    for (auto &p : be->deferred) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            out->kernel_ms[p.klass] += ms;
+            out->kernel_launches[p.klass] += 1;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    be->deferred.clear();
+    return RT_OK;
 }
 
 extern "C" uint32_t rt_scene_point_light_count(const RtDeviceScene *ds) { return ds ? ds->n_point_lights : 0; }

@@ -214,3 +214,28 @@ def test_corner_case_scenes(rt, backend, tmp_path, name):
         assert parity.image_metrics(fb.pixels, fb_o)["max_abs_diff"] <= 1
         assert stats.total_rays() == sum(cnt["rays"])
     dev.close()
+
+
+def test_deferred_kernel_timing(rt, backend, scene_path):
+    """RtRenderArgs.timed_classes + rt_collect_timings: frames in flight, one kernel class timed."""
+    import torch
+
+    scene = rt.parse_scene_file(scene_path("bunny_small"), image_width=200, image_height=150, recursion_depth=6)
+    dev = backend.upload(scene)
+    st = torch.cuda.Stream()
+    fb = torch.zeros(200 * 150 * 3, dtype=torch.float32, device="cuda")
+    ref, _, full = dev.render(3)
+    shadow = rt.KERNEL_CLASSES.index("trace_shadow")
+    a = dev.render_args(3)
+    a.timed_classes = 1 << shadow
+    with torch.cuda.stream(st):
+        for _ in range(5):
+            dev.render_device(a, fb.data_ptr(), stream=st.cuda_stream)
+    got = backend.collect_timings()
+    assert got.kernel_launches[shadow] == 5 * full.kernel_launches[shadow]
+    assert sum(got.kernel_launches) == got.kernel_launches[shadow]
+    assert 0.2 * full.kernel_ms[shadow] < got.kernel_ms[shadow] / 5 < 5.0 * full.kernel_ms[shadow]
+    assert np.array_equal(fb.cpu().numpy().reshape(150, 200, 3), ref.pixels)
+    again = backend.collect_timings()  # nothing pending any more
+    assert sum(again.kernel_launches) == 0
+    dev.close()

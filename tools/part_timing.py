@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""How long one GPU's share of a frame takes when the frame is split over N parts, with the frames
+enqueued back to back (no host synchronisation), against 1/N of the whole frame.
+
+    python3 tools/part_timing.py [workload] [frames]
+"""
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+
+    workload = sys.argv[1] if len(sys.argv) > 1 else "bunny"
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    bench = importlib.import_module("bench")
+    rt = importlib.import_module("rust-raytracer_amd")
+    importlib.import_module("scenes.gen_scenes").ensure_models()
+    scene_name, W, H, n, depth, tile, _ = bench.WORKLOADS[workload]
+    scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
+                                recursion_depth=depth)
+    be = rt.Backend(0)
+    dev = be.upload(scene)
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    whole = None
+    for parts in (1, 2, 4, 8):
+        worst = 0.0
+        for p in sorted({0, parts // 2, parts - 1}):
+            a = dev.render_args(n, tile=(tile, tile), part=(p, parts))
+            _, owned, stride = dev.partition_info(a)
+            buf = torch.zeros(max(stride * tile * tile * 3, W * H * 3), dtype=torch.float32, device="cuda")
+            for _ in range(3):
+                dev.render_device(a, buf.data_ptr(), stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                dev.render_device(a, buf.data_ptr(), stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            worst = max(worst, (time.perf_counter() - t0) / frames * 1e3)
+        if parts == 1:
+            whole = worst
+        print(f"{workload}: {parts} parts: slowest part {worst:.3f} ms per frame; ideal {whole / parts:.3f} ms; "
+              f"efficiency without the gather {whole / parts / worst:.2f}")
+    dev.close()
+    be.close()
+
+
+if __name__ == "__main__":
+    main()
