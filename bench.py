@@ -113,64 +113,75 @@ def main():
     scene_name, W, H, n, depth, tile, desc = WORKLOADS[args.workload]
     scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
                                 recursion_depth=depth)
-    backend = rt.Backend(local_rank)
+    # FLIGHTS frames are in flight at a time, each with a backend (ray queues), a stream and
+    # output buffers of its own: the tail of one frame's kernels (a few long-running waves) then
+    # overlaps the next frame's work instead of idling the GPU.  Measured on one MI355X for this
+    # frame cut into 8 parts: 0.54 ms per part-frame with one frame in flight, 0.28 ms with four
+    # (the whole frame: 1.82 -> 1.76 ms).
+    FLIGHTS = 4
+    backends = [rt.Backend(local_rank) for _ in range(FLIGHTS)]
     t_up = time.perf_counter()
-    dev = backend.upload(scene)
-    upload_s = time.perf_counter() - t_up
+    devs = [be.upload(scene) for be in backends]
+    upload_s = (time.perf_counter() - t_up) / FLIGHTS
+    dev = devs[0]
     mode = rt.RT_MODE_FAST if args.mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
     rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world))
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
     tile_floats = tile * tile * 3
 
-    # A stream of our own: the backend treats a null stream handle as "use the backend's private
+    # Streams of our own: the backend treats a null stream handle as "use the backend's private
     # stream", which would not be ordered with torch's copies and collectives.
-    main_stream = torch.cuda.Stream()
-    torch.cuda.set_stream(main_stream)
-    stream = main_stream.cuda_stream
-    assert stream != 0
+    streams = [torch.cuda.Stream() for _ in range(FLIGHTS)]
+    torch.cuda.set_stream(streams[0])
     staged = world > 1 and dist.get_backend() != "nccl"  # rehearsal on one GPU: gather through host memory (gloo)
+    counter = [0]
 
     if world == 1:
-        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        fbs = [torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") for _ in range(FLIGHTS)]
+        fb = fbs[0]
 
         def step(want_stats):
-            return dev.render_device(rargs, fb.data_ptr(), stream=stream, want_stats=want_stats)
+            b = counter[0] % FLIGHTS
+            counter[0] += 1
+            return devs[b].render_device(rargs, fbs[b].data_ptr(), stream=streams[b].cuda_stream, want_stats=want_stats)
 
         def drain():
             pass
     else:
-        # Two sets of buffers: while the gather of one frame is in flight the next frame renders.
+        # Per flight: the part buffer this rank renders into and, on rank 0, the gather target.
         part_floats = stride * tile_floats
-        part = [torch.zeros(part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        part = [torch.zeros(part_floats, dtype=torch.float32, device="cuda") for _ in range(FLIGHTS)]
         gathered = [torch.zeros(world * part_floats, dtype=torch.float32, device="cuda") if rank == 0 else None
-                    for _ in range(2)]
+                    for _ in range(FLIGHTS)]
         fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-        side = torch.cuda.Stream()  # rank 0: waits for a gather and restores the image layout
-        pending = [None, None]      # the gather that last read part[b] / wrote gathered[b]
-        untiled = [None, None]      # event: gathered[b] has been consumed
-        counter = [0]
+        side = torch.cuda.Stream()       # rank 0: waits for a gather and restores the image layout
+        pending = [None] * FLIGHTS       # the gather that last read part[b] / wrote gathered[b]
+        untiled = [None] * FLIGHTS       # event: gathered[b] has been consumed
 
         def step(want_stats):
-            b = counter[0] & 1
+            b = counter[0] % FLIGHTS
             counter[0] += 1
-            if pending[b] is not None:
-                pending[b].wait()  # stream-level: the gather of two frames ago has released part[b]
-            if untiled[b] is not None:
-                main_stream.wait_event(untiled[b])
-            st = dev.render_device(rargs, part[b].data_ptr(), stream=stream, want_stats=want_stats)
-            if staged:
-                host = part[b].cpu()
-                bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, bufs, dst=0)
-                if rank == 0:
-                    gathered[b].copy_(torch.cat(bufs))
-                    dev.untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=stream)
-                return st
-            pending[b] = dist.gather(part[b], list(gathered[b].chunk(world)) if rank == 0 else None, dst=0, async_op=True)
+            with torch.cuda.stream(streams[b]):
+                if pending[b] is not None:
+                    pending[b].wait()  # stream-level: the gather of FLIGHTS frames ago has released part[b]
+                if untiled[b] is not None:
+                    streams[b].wait_event(untiled[b])
+                st = devs[b].render_device(rargs, part[b].data_ptr(), stream=streams[b].cuda_stream, want_stats=want_stats)
+                if staged:
+                    host = part[b].cpu()
+                    bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, bufs, dst=0)
+                    if rank == 0:
+                        gathered[b].copy_(torch.cat(bufs))
+                        devs[b].untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=streams[b].cuda_stream)
+                        torch.cuda.current_stream().synchronize()  # the next flight's un-tile writes the same frame
+                    return st
+                pending[b] = dist.gather(part[b], list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
+                                         async_op=True)
             if rank == 0:
                 with torch.cuda.stream(side):
                     pending[b].wait()
-                    dev.untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=side.cuda_stream)
+                    devs[b].untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=side.cuda_stream)
                     untiled[b] = side.record_event()
             return st
 
@@ -178,7 +189,7 @@ def main():
             for w in pending:
                 if w is not None:
                     w.wait()
-            main_stream.wait_stream(side)
+            torch.cuda.current_stream().wait_stream(side)
 
     def fence():
         drain()
@@ -192,7 +203,7 @@ def main():
     # frames are enqueued back to back without waiting; only the dominant kernel class carries an
     # event pair there (its durations are collected after the loop for the roofline), because
     # every pair drains the pipeline for a few microseconds.
-    warm_stats = [step(True) for _ in range(max(args.warmup, 1))]
+    warm_stats = [step(True) for _ in range(max(args.warmup, FLIGHTS))]  # every flight at least once
     fence()
     k_warm = [warm_stats[-1].kernel_ms[k] for k in range(rt.RT_K_COUNT)]
     dom = max(range(len(rt.KERNEL_CLASSES)), key=lambda k: k_warm[k])
@@ -202,7 +213,12 @@ def main():
         step(False)
     fence()
     elapsed = time.perf_counter() - t0
-    timed = backend.collect_timings()
+    timed = rt.RtStats()
+    for be in backends:
+        part_t = be.collect_timings()
+        for k in range(rt.RT_K_COUNT):
+            timed.kernel_ms[k] += part_t.kernel_ms[k]
+            timed.kernel_launches[k] += part_t.kernel_launches[k]
     rargs.timed_classes = 0
     stats = warm_stats[-1:]  # the last warm-up frame: caches and clocks have settled
     rays_local = float(warm_stats[-1].total_rays() * args.steps)
@@ -212,7 +228,7 @@ def main():
     frame_check = None
     if world > 1 and rank == 0:
         whole = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
-        dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile)), whole.data_ptr(), stream=stream)
+        dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile)), whole.data_ptr(), stream=streams[0].cuda_stream)
         torch.cuda.synchronize()
         if not torch.equal(whole, fb):
             raise SystemExit(f"gathered frame differs from the single-GPU frame in {int((whole != fb).sum())} values")
@@ -253,6 +269,11 @@ def main():
                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, dom_name) if world == 1 else None,
                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                         "launches_timed": int(timed.kernel_launches[dom])}
+            # In the timed region the kernels of FLIGHTS frames share the GPU, so one launch lasts
+            # longer than it would alone.  The same kernel alone on the GPU (last warm-up frame):
+            alone_ms = k_ms[dom] / max(k_n[dom], 1)
+            alone = bytes_per_launch / (alone_ms * 1e-3) / 1e9
+            roofline["alone_on_the_gpu"] = {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS}
         out = {
             "metric": "rays/sec (all ray types), Stanford bunny 1000² spp9 d6, 1/2/4/8 GPUs",
             "value": value,
@@ -268,6 +289,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "traversal": args.mode, "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
+                       "frames_in_flight": FLIGHTS,
                        "scene_upload_ms": upload_s * 1e3,
                        "kernel_split_from": "warm-up frames (fully instrumented); roofline duration from the timed frames"},
             "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / n_stat for k in range(len(rt.KERNEL_CLASSES))},
@@ -288,8 +310,10 @@ def main():
                                              "sample": f"same scene at 1000x1000 rpp9, OpenMP over pixel columns, {dtN:.1f} s"}
         print(json.dumps(out), flush=True)
 
-    dev.close()
-    backend.close()
+    for d in devs:
+        d.close()
+    for be in backends:
+        be.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -2,7 +2,7 @@
 """How long one GPU's share of a frame takes when the frame is split over N parts, with the frames
 enqueued back to back (no host synchronisation), against 1/N of the whole frame.
 
-    python3 tools/part_timing.py [workload] [frames]
+    python3 tools/part_timing.py [workload] [frames] [frames in flight]
 """
 import importlib
 import os
@@ -24,31 +24,33 @@ def main():
     scene_name, W, H, n, depth, tile, _ = bench.WORKLOADS[workload]
     scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
                                 recursion_depth=depth)
-    be = rt.Backend(0)
-    dev = be.upload(scene)
-    st = torch.cuda.Stream()
-    torch.cuda.set_stream(st)
+    flights = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # frames in flight: one backend + stream each
+    bes = [rt.Backend(0) for _ in range(flights)]
+    devs = [b.upload(scene) for b in bes]
+    sts = [torch.cuda.Stream() for _ in range(flights)]
     whole = None
     for parts in (1, 2, 4, 8):
         worst = 0.0
         for p in sorted({0, parts // 2, parts - 1}):
-            a = dev.render_args(n, tile=(tile, tile), part=(p, parts))
-            _, owned, stride = dev.partition_info(a)
-            buf = torch.zeros(max(stride * tile * tile * 3, W * H * 3), dtype=torch.float32, device="cuda")
-            for _ in range(3):
-                dev.render_device(a, buf.data_ptr(), stream=st.cuda_stream)
+            a = devs[0].render_args(n, tile=(tile, tile), part=(p, parts))
+            _, owned, stride = devs[0].partition_info(a)
+            bufs = [torch.zeros(max(stride * tile * tile * 3, W * H * 3), dtype=torch.float32, device="cuda") for _ in range(flights)]
+            for k in range(3 * flights):
+                devs[k % flights].render_device(a, bufs[k % flights].data_ptr(), stream=sts[k % flights].cuda_stream)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(frames):
-                dev.render_device(a, buf.data_ptr(), stream=st.cuda_stream)
+            for k in range(frames):
+                devs[k % flights].render_device(a, bufs[k % flights].data_ptr(), stream=sts[k % flights].cuda_stream)
             torch.cuda.synchronize()
             worst = max(worst, (time.perf_counter() - t0) / frames * 1e3)
         if parts == 1:
             whole = worst
-        print(f"{workload}: {parts} parts: slowest part {worst:.3f} ms per frame; ideal {whole / parts:.3f} ms; "
-              f"efficiency without the gather {whole / parts / worst:.2f}")
-    dev.close()
-    be.close()
+        print(f"{workload}, {flights} frame(s) in flight: {parts} parts: slowest part {worst:.3f} ms per frame; "
+              f"ideal {whole / parts:.3f} ms; efficiency without the gather {whole / parts / worst:.2f}")
+    for d in devs:
+        d.close()
+    for b in bes:
+        b.close()
 
 
 if __name__ == "__main__":
