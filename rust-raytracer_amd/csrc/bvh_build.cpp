@@ -251,7 +251,6 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
             it.id = (int32_t)i;
         }
         out.blas.push_back(build_tree(std::move(items)));
-        out.verts64.insert(out.verts64.end(), mesh.vertices, mesh.vertices + mesh.n_triangles * 9);
     }
 
     // ---- scene-level tree (scene/mod.rs:699-700)
@@ -286,6 +285,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
     // ---- triangles in leaf order
     out.tris.resize((size_t)tri_total);
     out.tri_xf.resize((size_t)tri_total);
+    out.verts64.assign((size_t)tri_total * 12, 0.0);
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
         const RtMesh &mesh = scene.meshes[m];
         const Tree &t = out.blas[m];
@@ -302,6 +302,14 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
             tri.mesh = (int32_t)m;
             tri._pad = 0;
             triangle_map(v, out.tri_xf[(size_t)out.mesh_tri_base[m] + k]);
+            // f64 vertices and the unit normal normalize((b - a) x (c - a)) of triangle.rs:22, evaluated
+            // with the operation order of the device's D3 helpers (no contraction on either side)
+            double *w = &out.verts64[((size_t)out.mesh_tri_base[m] + k) * 12];
+            std::memcpy(w, v, 9 * sizeof(double));
+            const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+            const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const double len = std::sqrt((cx * cx + cy * cy) + cz * cz);
+            w[9] = cx / len; w[10] = cy / len; w[11] = cz / len;
         }
     }
 

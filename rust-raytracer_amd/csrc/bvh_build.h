@@ -39,7 +39,8 @@ struct FlatScene {
     std::vector<RtTri> tris;
     std::vector<RtTriXf> tri_xf;          // same order as `tris`
     std::vector<uint64_t> mesh_tri_base;  // first entry of `tris` / `verts64` triangle per mesh
-    std::vector<double> verts64;          // 9 doubles per triangle, FILE order, meshes concatenated
+    std::vector<double> verts64;          // 12 doubles per triangle, same order as `tris`: a, b, c and the
+                                          // unit normal Triangle::new stores (triangle.rs:22)
     int32_t tlas_root = 0;                // header node of the scene-level tree
     int stack_depth = 0;                  // traversal-stack entries a ray can need at most
     Tree tlas;                            // kept for structural tests

@@ -59,8 +59,8 @@ struct RtSceneView {
     const rt_f4 *tprim_xf;  // 3 per RtTPrim: rows of the instance's inverse transform (fp32), zeros otherwise
     const RtShape *shapes;
     const RtShape *protos;
-    const double *verts64;          // 9 doubles per mesh triangle, file order, meshes concatenated
-    const uint64_t *mesh_tri_base;  // first triangle of each mesh in verts64 / tris
+    const double *verts64;          // 12 doubles per mesh triangle, same order as tris: a, b, c, unit normal
+    const uint64_t *mesh_tri_base;  // first triangle of each mesh in tris / tri_xf / verts64
     const RtShader *shaders;
     const RtLight *lights;
     const int32_t *point_lights;    // indices into lights[] of the point lights, in order
@@ -248,11 +248,10 @@ RT_HD bool exact_prim_hit(const RtSceneView &S, int32_t shape_id, int32_t gtri, 
     }
     case RT_SHAPE_MESH: {
         if (gtri < 0) break;
-        const RtTri *rec = reinterpret_cast<const RtTri *>(S.tris) + gtri;
-        const double *v = S.verts64 + (S.mesh_tri_base[rec->mesh] + (uint64_t)rec->orig) * 9;
+        const double *v = S.verts64 + (size_t)gtri * 12;
         const D3 a = d3(v[0], v[1], v[2]), b = d3(v[3], v[4], v[5]), c = d3(v[6], v[7], v[8]);
         got = triangle_f64(a, b, c, o, d, tmin, tmax, forced, t);
-        if (got && normal_out) n = normalize(cross(b - a, c - a));
+        if (got && normal_out) n = d3(v[9], v[10], v[11]);  // computed once per triangle, as Triangle::new does
         break;
     }
     default: break;
@@ -855,12 +854,19 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
 // The f64 test of a secondary ray against the primitive it starts on, with the
 // reference's own arithmetic.  A triangle can never be re-hit from a point in its
 // own plane (t = 0 < t_min), so only spheres and boxes are tested.
+//
+// `outward`: the ray leaves the surface on the side of the normal.  A sphere's hit point lies
+// on the sphere, so an outward ray cannot meet it again (its second root is rounding noise
+// around t = 0, far below t_min) and the test is skipped.  A box is always tested: for a ray
+// that started inside it the reference reports the "hit" at t_min, a point INSIDE the box
+// (cuboid.rs:63-73 with bbox.rs:124), from which every direction hits the box again.
 RT_HD bool self_hit_f64(const RtSceneView &S, int32_t org_shape, const D3 &o, const D3 &d, double tmin, double tmax,
-                        double &t_out) {
+                        bool outward, double &t_out) {
     if (org_shape < 0) return false;
     const RtShape *sh = &S.shapes[org_shape];
     const int32_t pt = sh->type == RT_SHAPE_INSTANCE ? S.protos[sh->proto].type : sh->type;
     if (pt != RT_SHAPE_SPHERE && pt != RT_SHAPE_BOX) return false;
+    if (pt == RT_SHAPE_SPHERE && outward) return false;
     return exact_prim_hit(S, org_shape, -1, o, d, tmin, tmax, false, 0.0, t_out, nullptr);
 }
 

@@ -265,8 +265,8 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
             // Hit::to_light (hit_struct.rs:29-39) against the primitive the shadow ray starts on
             for (int ls = 0; ls < S.n_point_lights; ++ls) {
                 const D3 dir = d3(S.lights[S.point_lights[ls]].position) - p;  // Ray::atob, ray.rs:15-20
-                double st;
-                const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, st);
+                double st = 0.0;
+                const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, st);
                 const size_t k = (size_t)ls * Q.capacity + (size_t)sample;
                 Q.occ_t[k] = self ? (float)st : 1.0f;
                 Q.occ_shape[k] = self ? shape : -1;
@@ -286,7 +286,8 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         tmp.shape = shape;
         tmp.tri = gtri;
         double st;
-        tmp.self_t = self_hit_f64(S, shape, tmp.p, tmp.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), st)
+        tmp.self_t = self_hit_f64(S, shape, tmp.p, tmp.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(),
+                                  dot(n, tmp.d) > 0.0, st)
                          ? (float)st
                          : __builtin_inff();
         return RT_ACT_MIRROR;
