@@ -51,7 +51,7 @@ struct RtBuffers {
     // [point light slot * capacity + sample]: blocker, -1 = light visible
     int32_t *occ_shape;
     int32_t *occ_tri;
-    float *occ_t;     // in: t of the origin primitive's re-hit or 1.0; (reference-order mode) out: blocker t
+    float *occ_t;     // t of the origin primitive's re-hit, valid where occ_shape >= 0 after the shade stage
     // colour of each local sample, 3 floats
     float *color;
     // device counters, see RT_CNT_*
@@ -268,9 +268,11 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
                 double st = 0.0;
                 const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, st);
                 const size_t k = (size_t)ls * Q.capacity + (size_t)sample;
-                Q.occ_t[k] = self ? (float)st : 1.0f;
                 Q.occ_shape[k] = self ? shape : -1;
-                Q.occ_tri[k] = -1;
+                if (self) {  // rare; the other two arrays are only read where occ_shape says "blocked"
+                    Q.occ_t[k] = (float)st;
+                    Q.occ_tri[k] = -1;
+                }
             }
         }
         return RT_ACT_NONE;
@@ -319,8 +321,8 @@ RT_HD bool shadow_setup(const RtSceneView &S, const RtBuffers &Q, uint32_t light
     r.org_shape = Q.l_shape[sample];
     if (r.org_shape < 0) return false;
     const size_t k = (size_t)light_slot * Q.capacity + sample;
-    r.t0 = Q.occ_t[k];  // 1.0 (Hit::to_light), or the origin primitive's own re-hit
     r.shape0 = Q.occ_shape[k];
+    r.t0 = r.shape0 >= 0 ? Q.occ_t[k] : 1.0f;  // the origin primitive's own re-hit, or Hit::to_light's 1.0
     if (ANYHIT && r.shape0 >= 0) return false;
     r.org_tri = Q.l_tri[sample];
     const RtLight &light = S.lights[S.point_lights[light_slot]];
@@ -335,7 +337,7 @@ RT_HD bool shadow_setup(const RtSceneView &S, const RtBuffers &Q, uint32_t light
 RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample, RaySetup &r) {
     const size_t k = (size_t)light_slot * Q.capacity + sample;
     const int32_t org_shape = Q.l_shape[sample], org_tri = Q.l_tri[sample], shape0 = Q.occ_shape[k];
-    const float t0 = Q.occ_t[k];
+    const float t0 = 1.0f;  // Hit::to_light; a sample whose own primitive blocks the light is not traced at all
     const double px = Q.l_p[0][sample], py = Q.l_p[1][sample], pz = Q.l_p[2][sample];
     const RtLight &light = S.lights[S.point_lights[light_slot]];
     r.org_shape = org_shape;
@@ -350,7 +352,7 @@ RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t l
 RT_HD void shadow_store(const RtBuffers &Q, uint32_t light_slot, uint32_t sample, int32_t shape, int32_t tri) {
     const size_t k = (size_t)light_slot * Q.capacity + sample;
     Q.occ_shape[k] = shape;
-    Q.occ_tri[k] = tri;
+    if (shape >= 0) Q.occ_tri[k] = tri;  // only read where occ_shape says "blocked"
 }
 
 template <class Stack, bool ORDERED, bool ANYHIT, bool EXACT>
@@ -418,7 +420,7 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
             visible = blocker < 0;
             if (ids.shadow_shape) ids.shadow_shape[gs * (size_t)S.n_point_lights + slot] = blocker;
             if (ids.shadow_tri)
-                ids.shadow_tri[gs * (size_t)S.n_point_lights + slot] = tri_file_index(S, Q.occ_tri[k]);
+                ids.shadow_tri[gs * (size_t)S.n_point_lights + slot] = blocker >= 0 ? tri_file_index(S, Q.occ_tri[k]) : -1;
         }
         if (visible) add_light(sh, light, n, d3(light.position) - p, d, color);
         ++slot;
