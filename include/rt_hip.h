@@ -71,7 +71,10 @@ void rt_scene_destroy(RtScene *scene);
 typedef struct RtBackend RtBackend;
 typedef struct RtDeviceScene RtDeviceScene;
 
-/* One backend per GPU.  `device_ordinal` is the HIP device index. */
+/* A backend owns the ray queues and work buffers of ONE frame in flight on one GPU
+ * (`device_ordinal` is the HIP device index).  Calls on one backend must not overlap
+ * (one host thread at a time, and the frames it enqueues run one after the other); to keep
+ * several frames in flight on a GPU create several backends and give each its own stream. */
 int rt_backend_create(int device_ordinal, RtBackend **backend_out);
 void rt_backend_destroy(RtBackend *backend);
 

@@ -1,12 +1,16 @@
 // rt_backend.hip -- gfx950 kernels of the wavefront pipeline and the C ABI
 // around them (include/rt_hip.h).  Built for MI355X only.
 //
-// Kernel shape, common to every queue-consuming stage: a fixed grid of
-// 256-thread blocks walks its queue with a grid-stride loop; the queue length
-// lives in device memory (written by the previous stage's wave-wide ballot
-// allocations), so no stage needs a host round trip to learn its size.
-// Traversal kernels keep a per-lane stack in LDS, laid out [entry][thread] so a
-// wave's accesses to one stack level fall on 64 consecutive dwords.
+// Launch shapes:
+//   * camera rays and shadow rays (fast mode): one 64-thread block = one wave = one packet of
+//     64 rays (rt_packet.h); blocks beyond the work of a launch return at once, because the
+//     number of lit hits is only known on the device;
+//   * mirror bounces and the reference-order mode: 256-thread blocks, one ray per lane, with a
+//     per-lane traversal stack in LDS laid out [entry][thread] so that a wave's accesses to one
+//     stack level fall on 64 consecutive dwords; a queue's length lives in device memory
+//     (written by the previous stage's wave-wide ballot allocations), so no stage needs a host
+//     round trip to learn its size;
+//   * shade / accumulate / resolve: one thread per sample or pixel.
 
 #include <hip/hip_runtime.h>
 

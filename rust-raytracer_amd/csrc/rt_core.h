@@ -548,8 +548,7 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
 //     reference does.  The test only culls; primitives decide hits.
 //   * triangle test: the four determinants of triangle.rs:76-105 share their two cross
 //     products and one reciprocal of det A replaces the three divisions.
-// It is a resumable state machine (begin / step) so that a kernel can hand a finished
-// lane its next ray while the other lanes of the wave keep traversing.
+// It is written as begin / step: one step walks inner nodes to the next leaf and processes it.
 
 // Pairs of floats as the packed fp32 instructions (v_pk_fma_f32: two multiply-adds per lane per
 // instruction) take them: an aligned register pair on the device, a plain struct on the host.

@@ -183,7 +183,7 @@ RT_HD void trace_closest_body(const RtSceneView &S, const RtBuffers &Q, const Rt
     closest_store(Q, idx, hit.t, hit.shape, hit.tri);
 }
 
-// Fast mode, one ray start to finish (what a lane of the persistent kernel does between refills).
+// Fast mode, one ray per lane, start to finish (mirror bounces; the packet kernels replace it for coherent rays).
 template <class Stack>
 RT_HD void trace_closest_fast_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, int bounce,
                                    uint32_t idx, Stack &stk) {
