@@ -110,11 +110,14 @@ typedef struct RtRenderArgs {
     int32_t antialias_method;     /* render.rs:10 */
     int32_t mode;                 /* RT_MODE_* */
     /* Image partition for multi-GPU rendering.  The image is cut into
-     * tile_w x tile_h tiles, numbered row-major, and dealt round-robin: tile k
-     * belongs to part k % part_count, or (k + r) % part_count for tile-row r when
-     * a row holds a multiple of part_count tiles (so that no part owns whole
-     * columns).  Part sizes differ by at most one tile; rt_partition_tiles lists
-     * them.  part_count <= 1 renders everything. */
+     * tile_w x tile_h tiles; tile (tx, ty) belongs to part
+     * (tx + skew * ty) % part_count, where skew is chosen per tile grid and part
+     * count so that part sizes are as equal as a lattice allows (they differ by
+     * at most a tile or two) and a part's tiles are spread evenly over the
+     * image in both directions (8 parts: skew 3, nearest tiles of a part 2.8
+     * tiles apart).  rt_partition_tiles lists a part's tiles (row-major tile
+     * numbers, ascending); rt_partition_info gives the counts.
+     * part_count <= 1 renders everything. */
     uint32_t tile_w, tile_h;      /* 0 -> 32 */
     uint32_t part_index, part_count;
 } RtRenderArgs;

@@ -435,11 +435,10 @@ uint32_t grid_for(uint64_t work) {
 // Tiles owned by `part` of `parts` (rt_tile_owner), ascending.
 void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t parts, std::vector<int32_t> &out) {
     out.clear();
+    const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
-        for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-            const uint32_t k = ty * tiles_x + tx;
-            if (rt_tile_owner(k, ty, tiles_x, parts) == part) out.push_back((int32_t)k);
-        }
+        for (uint32_t tx = 0; tx < tiles_x; ++tx)
+            if (rt_tile_owner(tx, ty, parts, skew) == part) out.push_back((int32_t)(ty * tiles_x + tx));
 }
 
 typedef RtEventPair EventPair;
@@ -554,8 +553,8 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         RT_HIP(hipEventRecord(ev0, stream));
     }
     const bool ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
-    uint32_t xcd_chunk = 128;
-    if (const char *e = std::getenv("RT_XCD_CHUNK")) xcd_chunk = (uint32_t)std::max(1, std::atoi(e));
+    uint32_t xcd_chunk_fixed = 0;
+    if (const char *e = std::getenv("RT_XCD_CHUNK")) xcd_chunk_fixed = (uint32_t)std::max(1, std::atoi(e));
     const int max_bounce = ds->has_mirror ? S.recursion_depth : 0;
     std::vector<uint32_t> host_counters;
     // fast mode: wave packets for camera and shadow rays (RT_PACKET=0 keeps the per-lane kernels, for comparison)
@@ -579,6 +578,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+        // chunk of the XCD remap, in 256-sample blocks: 128 (a few tiles) for a whole frame, smaller
+        // for a small launch so that every XCD still gets >= 32 chunks -- chunks differ in cost, and
+        // with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
+        const uint32_t xcd_chunk = xcd_chunk_fixed ? xcd_chunk_fixed : std::min(128u, std::max(8u, full_grid / 256u));
         for (int bounce = 0; bounce <= max_bounce; ++bounce) {
             // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
             // the device, so a fixed grid strides over it (and costs little when it is empty).
@@ -919,8 +922,9 @@ extern "C" int rt_partition_info(uint32_t width, uint32_t height, const RtRender
     if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
     const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
     std::vector<uint32_t> per_part(parts, 0);
+    const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
-        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_owner(ty * tiles_x + tx, ty, tiles_x, parts)]++;
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_owner(tx, ty, parts, skew)]++;
     if (tiles_total) *tiles_total = tiles_x * tiles_y;
     if (tiles_owned) *tiles_owned = per_part[args->part_index];
     if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());
@@ -957,9 +961,10 @@ extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, 
     const uint32_t key[5] = {width, height, tw, th, parts};
     if (std::memcmp(key, be->untile_key, sizeof(key)) != 0 || !be->tile_where) {
         std::vector<uint32_t> where((size_t)tiles_x * tiles_y), next(parts, 0);
+        const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
         for (uint32_t ty = 0; ty < tiles_y; ++ty)
             for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-                const uint32_t k = ty * tiles_x + tx, p = rt_tile_owner(k, ty, tiles_x, parts);
+                const uint32_t k = ty * tiles_x + tx, p = rt_tile_owner(tx, ty, parts, skew);
                 where[k] = p * stride + next[p]++;
             }
         if (be->tile_where) (void)hipFree(be->tile_where);

@@ -44,13 +44,48 @@ RT_TYPES_INL int32_t rt_make_leaf_ref(uint32_t first, uint32_t count) {
     return ~(int32_t)((first << 3) | count);
 }
 
-// Owner of tile k = ty * tiles_x + tx in a frame split over `parts` devices.  Tiles are dealt
-// round-robin in row-major order, so part sizes differ by at most one tile; when a tile row holds
-// a whole number of rounds the deal is shifted by one per row, which keeps a part from owning
-// whole columns of the image.
-RT_TYPES_INL uint32_t rt_tile_owner(uint32_t k, uint32_t ty, uint32_t tiles_x, uint32_t parts) {
+// Owner of tile (tx, ty) in a frame split over `parts` devices: (tx + skew * ty) % parts, a
+// lattice.  A part's tiles then lie on a regular oblique grid, and how evenly that grid samples
+// the image decides how evenly the cost of a frame (which varies smoothly over the image) is
+// shared.  rt_tile_skew picks the skew for a tile grid: first the skews that give the parts the
+// most equal tile counts, among those the one whose lattice has the longest shortest vector
+// (skew 1 would put a part's tiles on diagonals 'parts' tiles apart; for 8 parts skew 3 spaces
+// them 2.8 tiles apart in every direction), then the smallest.
+RT_TYPES_INL uint32_t rt_tile_owner(uint32_t tx, uint32_t ty, uint32_t parts, uint32_t skew) {
+    return parts <= 1 ? 0u : (uint32_t)(((uint64_t)skew * ty + tx) % parts);
+}
+
+inline uint32_t rt_tile_skew(uint32_t tiles_x, uint32_t tiles_y, uint32_t parts) {
     if (parts <= 1) return 0;
-    return (k + (tiles_x % parts == 0 ? ty : 0u)) % parts;
+    static thread_local uint32_t memo_key[3] = {0, 0, 0}, memo_val = 0;
+    if (memo_key[0] == tiles_x && memo_key[1] == tiles_y && memo_key[2] == parts) return memo_val;
+    uint32_t best = 1, best_max = ~0u, best_len = 0;
+    for (uint32_t s = 1; s < parts; ++s) {
+        // tile counts: every part gets tiles_x / parts per row, the first tiles_x % parts owners of a row one more
+        uint32_t most = 0;
+        for (uint32_t p = 0; p < parts; ++p) {
+            uint32_t extra = 0;
+            for (uint32_t ty = 0; ty < tiles_y; ++ty) {
+                const uint32_t first = (uint32_t)(((uint64_t)s * ty) % parts);  // owner of tx = 0 (and of tx = q * parts)
+                extra += (p + parts - first) % parts < tiles_x % parts ? 1u : 0u;
+            }
+            most = extra > most ? extra : most;
+        }
+        // shortest non-zero (a, b) with a + s * b = 0 (mod parts)
+        uint32_t len = parts * parts;  // (parts, 0) is always in the lattice
+        for (uint32_t b = 0; b <= parts; ++b)
+            for (uint32_t a = 0; a < parts; ++a) {  // a and a - parts are the two candidates of smallest |a|
+                if ((a + (uint64_t)s * b) % parts != 0 || (a == 0 && b == 0)) continue;
+                const uint32_t m = a < parts - a ? a : parts - a;
+                const uint32_t l = m * m + b * b;
+                len = l < len ? l : len;
+            }
+        if (most < best_max || (most == best_max && len > best_len)) {
+            best = s; best_max = most; best_len = len;
+        }
+    }
+    memo_key[0] = tiles_x; memo_key[1] = tiles_y; memo_key[2] = parts; memo_val = best;
+    return best;
 }
 
 // Top-level primitive, 64 bytes, stored in leaf order of the scene-level tree.

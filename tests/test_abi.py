@@ -71,24 +71,34 @@ def test_host_only_entry_points_need_no_gpu(rt):
 
 
 def test_partition_is_balanced_and_interleaved(rt):
-    """Round-robin deal: part sizes differ by at most one tile, every part has tiles in every tile
-    row and (when there are enough columns) every tile column of the image."""
+    """Lattice deal: part sizes differ by at most one tile on these grids, every window of
+    `parts` consecutive tiles of a tile row holds every part once, and a part's tiles keep their
+    distance from each other in both directions (no part owns neighbouring tiles or whole diagonals)."""
     for width, tile in ((1000, 40), (1024, 32), (640, 40)):
         tiles_x = (width + tile - 1) // tile
         for parts in (2, 3, 4, 8):
             counts = []
             everything = []
+            owner = np.full(tiles_x * tiles_x, -1)
             for p in range(parts):
                 a = rt.RtRenderArgs()
                 a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count = 3, tile, tile, p, parts
                 t = rt.partition_tiles(width, width, a)
                 counts.append(t.size)
                 everything.append(t)
+                owner[t] = p
                 assert (np.diff(t) > 0).all()
                 assert len(set((t // tiles_x).tolist())) == tiles_x  # present in every tile row
-                assert len(set((t % tiles_x).tolist())) == tiles_x  # and in every tile column
             assert max(counts) - min(counts) <= 1, (width, tile, parts, counts)
             assert sorted(np.concatenate(everything).tolist()) == list(range(tiles_x * tiles_x))
+            owner = owner.reshape(tiles_x, tiles_x)
+            for x in range(tiles_x - parts + 1):
+                assert sorted(owner[3, x:x + parts].tolist()) == list(range(parts))
+            # shortest distance between two tiles of part 0, squared: 2 parts -> 2 (checkerboard), 8 parts -> 8
+            ys, xs = np.nonzero(owner == 0)
+            d2 = (ys[:, None] - ys[None, :]) ** 2 + (xs[:, None] - xs[None, :]) ** 2
+            d2[d2 == 0] = 10 ** 6
+            assert d2.min() >= {2: 2, 3: 2, 4: 2, 8: 8}[parts], (width, tile, parts, d2.min())
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

@@ -22,6 +22,8 @@ def main():
     rt = importlib.import_module("rust-raytracer_amd")
     importlib.import_module("scenes.gen_scenes").ensure_models()
     scene_name, W, H, n, depth, tile, _ = bench.WORKLOADS[workload]
+    tile = int(os.environ.get("RT_TILE", tile))
+    every = os.environ.get("RT_ALL_PARTS", "0") == "1"  # time every part instead of first / middle / last
     scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
                                 recursion_depth=depth)
     flights = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # frames in flight: one backend + stream each
@@ -30,8 +32,9 @@ def main():
     sts = [torch.cuda.Stream() for _ in range(flights)]
     whole = None
     for parts in (1, 2, 4, 8):
-        worst = 0.0
-        for p in sorted({0, parts // 2, parts - 1}):
+        worst = host = 0.0
+        each = []
+        for p in (range(parts) if every else sorted({0, parts // 2, parts - 1})):
             a = devs[0].render_args(n, tile=(tile, tile), part=(p, parts))
             _, owned, stride = devs[0].partition_info(a)
             bufs = [torch.zeros(max(stride * tile * tile * 3, W * H * 3), dtype=torch.float32, device="cuda") for _ in range(flights)]
@@ -41,12 +44,16 @@ def main():
             t0 = time.perf_counter()
             for k in range(frames):
                 devs[k % flights].render_device(a, bufs[k % flights].data_ptr(), stream=sts[k % flights].cuda_stream)
+            enq = (time.perf_counter() - t0) / frames * 1e3  # host time to enqueue one frame
             torch.cuda.synchronize()
-            worst = max(worst, (time.perf_counter() - t0) / frames * 1e3)
+            each.append((time.perf_counter() - t0) / frames * 1e3)
+            worst = max(worst, each[-1])
+            host = max(host, enq)
         if parts == 1:
             whole = worst
         print(f"{workload}, {flights} frame(s) in flight: {parts} parts: slowest part {worst:.3f} ms per frame; "
-              f"ideal {whole / parts:.3f} ms; efficiency without the gather {whole / parts / worst:.2f}")
+              f"ideal {whole / parts:.3f} ms; efficiency without the gather {whole / parts / worst:.2f}; "
+              f"host enqueue {host:.3f} ms per frame" + (f"; parts {' '.join(f'{e:.3f}' for e in each)}" if every else ""))
     for d in devs:
         d.close()
     for b in bes:
