@@ -3,7 +3,7 @@
 // call sequence (main.rs:51-104): read scene -> parse_scene -> render -> save.
 //
 //   rt-cli -i scene.json [-o out.png] [-x W] [-y H] [-r RPP] [-d DEPTH] [--aspect-ratio A]
-//          [--disable-shadows] [--render-normals] [--antialias-method normal|jittered|random]
+//          [--disable-shadows] [--render-normals] [--antialias-method normal|jittered|random] [--seed N]
 //          [--backend hip] [--device N] [--mode fast|reference] [--stats-json FILE]
 //
 // Only the HIP backend exists in this program; there is no CPU renderer to fall back to.
@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,9 @@ void usage() {
                  "  -d, --recursion-depth <DEPTH>       [default: 3]\n"
                  "      --aspect-ratio <ASPECT_RATIO>\n      --disable-shadows\n      --render-normals\n"
                  "      --antialias-method <normal|jittered|random>\n"
+                 "      --seed <N>                      key of the jittered / random sample offsets\n"
+                 "                                      [default: drawn from the operating system, as the\n"
+                 "                                      reference's thread_rng is]\n"
                  "      --backend <hip>                 [default: hip]\n"
                  "      --device <ORDINAL>              [default: 0]\n"
                  "      --mode <fast|reference>         traversal order [default: fast]\n"
@@ -54,6 +58,8 @@ int main(int argc, char **argv) {
     std::string scene_path, output = "out.png", stats_json, backend = "hip";
     long rays_per_pixel = 4;  // DEFAULT_RAYS_PER_PIXEL, prelude.rs:56
     int aa = RT_AA_NORMAL, mode = RT_MODE_FAST, device = 0;
+    bool have_seed = false;
+    uint64_t seed = 0;
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -79,6 +85,9 @@ int main(int argc, char **argv) {
             else if (v == "jittered") aa = RT_AA_JITTERED;
             else if (v == "random") aa = RT_AA_RANDOM;
             else return fail("invalid value '" + v + "' for '--antialias-method'");
+        } else if (a == "--seed") {
+            seed = std::strtoull(value("--seed"), nullptr, 10);
+            have_seed = true;
         } else if (a == "--backend") backend = value("--backend");
         else if (a == "--device") device = (int)std::strtol(value("--device"), nullptr, 10);
         else if (a == "--mode") {
@@ -124,6 +133,11 @@ int main(int argc, char **argv) {
     std::memset(&ra, 0, sizeof(ra));
     ra.sqrt_rays_per_pixel = (uint16_t)n;
     ra.antialias_method = aa;
+    if (!have_seed) {  // antialias.rs:47-48 draws from rand::thread_rng(): a different frame every run
+        std::random_device rd;
+        seed = ((uint64_t)rd() << 32) | rd();
+    }
+    ra.seed = seed;
     ra.mode = mode;
     const uint32_t W = scene->image_width, H = scene->image_height;
     std::vector<float> fb((size_t)W * H * 3);

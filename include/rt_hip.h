@@ -89,8 +89,18 @@ void rt_scene_free(RtDeviceScene *dev_scene);
 /* render                                                               */
 /* ------------------------------------------------------------------ */
 
-/* antialias.rs:6-10.  Only NORMAL is deterministic; the other two draw from
- * an OS-seeded RNG in the reference and are rejected with RT_ERR_UNSUPPORTED. */
+/* antialias.rs:6-10, 38-57.  Offsets (di, dj) of sample (p, q) inside its pixel:
+ *   NORMAL    ((p + 0.5) / n, (q + 0.5) / n)
+ *   JITTERED  ((p + r1) / n, (q + r2) / n)
+ *   RANDOM    (r1, r2)
+ * with r1, r2 uniform in [0, 1).  The reference draws them from rand::thread_rng(), which
+ * is seeded by the operating system, so no two of its runs agree; here they come from a
+ * counter-based generator, Philox4x32-10 with key = RtRenderArgs.seed (low word, high
+ * word) and counter = (sample index low word, high word, 0, 0), sample index =
+ * (i + j * width) * n * n + p * n + q.  Of the four output words x0..x3,
+ * r1 = ((x0 << 32 | x1) >> 11) * 2^-53 and r2 likewise from x2, x3 (53 random bits, like
+ * rand's f64).  A frame therefore depends only on (scene, n, method, seed): not on the
+ * tiling, the partition over GPUs or the traversal mode. */
 enum { RT_AA_NORMAL = 0, RT_AA_JITTERED = 1, RT_AA_RANDOM = 2 };
 
 /* Traversal policy.  Both produce the same closest hits except at exact ties.
@@ -120,6 +130,8 @@ typedef struct RtRenderArgs {
      * part_count <= 1 renders everything. */
     uint32_t tile_w, tile_h;      /* 0 -> 32 */
     uint32_t part_index, part_count;
+    uint32_t reserved0;           /* 0 */
+    uint64_t seed;                /* key of the sample-offset generator (JITTERED / RANDOM) */
 } RtRenderArgs;
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is

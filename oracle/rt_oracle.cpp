@@ -671,11 +671,68 @@ Color apply_shader(const Hit<Real> &hit) {
     }
 }
 
+// ---------------------------------------------------------------- antialias.rs
+
+// The reference's jittered / random methods call rand::thread_rng().gen::<Real>() (antialias.rs:45-57),
+// an OS-seeded generator: its numbers cannot be reproduced.  The oracle keeps the reference's
+// FORMULAS and takes the uniform numbers from Philox4x32-10 (Salmon et al., SC'11: the round is
+// (c0, c1, c2, c3) -> (hi(M1*c2)^c1^k0, lo(M1*c2), hi(M0*c0)^c3^k1, lo(M0*c0)), M0 = 0xD2511F53,
+// M1 = 0xCD9E8D57, ten rounds, key += (0x9E3779B9, 0xBB67AE85) between rounds), keyed by a seed
+// and counted by the frame-wide sample index, so that another implementation can draw the same.
+struct Philox {
+    uint32_t ctr[4];
+    uint32_t key[2];
+    void round_once() {
+        const uint64_t p0 = 0xD2511F53ull * ctr[0];
+        const uint64_t p1 = 0xCD9E8D57ull * ctr[2];
+        const uint32_t next[4] = {(uint32_t)(p1 >> 32) ^ ctr[1] ^ key[0], (uint32_t)(p1 & 0xffffffffull),
+                                  (uint32_t)(p0 >> 32) ^ ctr[3] ^ key[1], (uint32_t)(p0 & 0xffffffffull)};
+        std::memcpy(ctr, next, sizeof(ctr));
+    }
+    void run() {
+        round_once();
+        for (int r = 1; r < 10; ++r) {
+            key[0] += 0x9E3779B9u;
+            key[1] += 0xBB67AE85u;
+            round_once();
+        }
+    }
+};
+
+// rand 0.8.5 Standard for f64: 53 random bits scaled into [0, 1)
+double unit_from_bits(uint32_t hi, uint32_t lo) {
+    const uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
+    return (double)(bits >> 11) / 9007199254740992.0;
+}
+
+// antialias.rs:26-57.  method: 0 normal, 1 jittered, 2 random.
+template <typename Real>
+void antialias(int method, uint64_t seed, uint64_t sample, uint16_t n, uint16_t p, uint16_t q, Real &di, Real &dj) {
+    if (method == 0) {  // antialias.rs:38-43
+        di = ((Real)p + (Real)0.5) / (Real)n;
+        dj = ((Real)q + (Real)0.5) / (Real)n;
+        return;
+    }
+    Philox g{{(uint32_t)(sample & 0xffffffffull), (uint32_t)(sample >> 32), 0u, 0u},
+             {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)}};
+    g.run();
+    const Real r1 = (Real)unit_from_bits(g.ctr[0], g.ctr[1]);
+    const Real r2 = (Real)unit_from_bits(g.ctr[2], g.ctr[3]);
+    if (method == 1) {  // antialias.rs:45-50
+        di = ((Real)p + r1) / (Real)n;
+        dj = ((Real)q + r2) / (Real)n;
+    } else {  // antialias.rs:52-57
+        di = r1;
+        dj = r2;
+    }
+}
+
 // ---------------------------------------------------------------- render.rs
 
 template <typename Real>
-int render_impl(const RtScene &rs, uint16_t n, int threads, float *fb, const OracleOutputs *out,
-                OracleCounters *counters_out) {
+int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int threads, float *fb,
+                const OracleOutputs *out, OracleCounters *counters_out) {
+    if (aa_method < 0 || aa_method > 2) return -1;
     for (uint32_t i = 0; i < rs.n_shaders; ++i)
         if (rs.shaders[i].type == RT_SHADER_GGX_MIRROR) return -3;
     Scene<Real> scene(rs);
@@ -699,9 +756,8 @@ int render_impl(const RtScene &rs, uint16_t n, int threads, float *fb, const Ora
                 for (uint16_t p = 0; p < n; ++p) {
                     for (uint16_t q = 0; q < n; ++q) {
                         const size_t s = ((size_t)i + (size_t)j * W) * spp + (size_t)p * n + q;
-                        // antialias.rs:38-43
-                        const Real di = ((Real)p + (Real)0.5) / (Real)n;
-                        const Real dj = ((Real)q + (Real)0.5) / (Real)n;
+                        Real di, dj;  // render.rs:66
+                        antialias<Real>(aa_method, seed, (uint64_t)s, n, p, q, di, dj);
                         Hit<Real> hit = Hit<Real>::make(scene.camera.generate_ray(i, j, di, dj), &scene);
                         hit.counters = &local;
                         SampleRecord rec;
@@ -804,8 +860,29 @@ extern "C" {
 int oracle_render(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int geometry_bits, int threads,
                   float *fb_rgb, const OracleOutputs *outputs, OracleCounters *counters) {
     if (!scene || !fb_rgb || sqrt_rays_per_pixel == 0) return -1;
-    if (geometry_bits == 32) return render_impl<float>(*scene, sqrt_rays_per_pixel, threads, fb_rgb, outputs, counters);
-    return render_impl<double>(*scene, sqrt_rays_per_pixel, threads, fb_rgb, outputs, counters);
+    return oracle_render_aa(scene, sqrt_rays_per_pixel, 0, 0, geometry_bits, threads, fb_rgb, outputs, counters);
+}
+
+int oracle_render_aa(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int antialias_method, uint64_t seed,
+                     int geometry_bits, int threads, float *fb_rgb, const OracleOutputs *outputs,
+                     OracleCounters *counters) {
+    if (!scene || !fb_rgb || sqrt_rays_per_pixel == 0) return -1;
+    if (geometry_bits == 32)
+        return render_impl<float>(*scene, sqrt_rays_per_pixel, antialias_method, seed, threads, fb_rgb, outputs, counters);
+    return render_impl<double>(*scene, sqrt_rays_per_pixel, antialias_method, seed, threads, fb_rgb, outputs, counters);
+}
+
+// The generator alone: out = Philox4x32-10(counter, key).
+void oracle_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    Philox g{{counter[0], counter[1], counter[2], counter[3]}, {key[0], key[1]}};
+    g.run();
+    std::memcpy(out, g.ctr, sizeof(g.ctr));
+}
+
+// antialias.rs:26-57 for one sample.
+void oracle_sample_offsets(int method, uint64_t seed, uint64_t sample, uint16_t n, uint16_t p, uint16_t q, double *di,
+                           double *dj) {
+    antialias<double>(method, seed, sample, n, p, q, *di, *dj);
 }
 
 int oracle_trace_rays(const RtScene *scene, uint64_t n, const double *origins, const double *directions,

@@ -39,6 +39,18 @@ typedef struct OracleCounters {
 int oracle_render(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int geometry_bits, int threads,
                   float *fb_rgb, const OracleOutputs *outputs, OracleCounters *counters);
 
+/* The same with antialias.rs's three methods (0 normal, 1 jittered, 2 random).  The uniform
+ * numbers of the two stochastic methods come from Philox4x32-10 keyed by `seed` and counted by
+ * the frame-wide sample index (the reference's own generator is OS-seeded). */
+int oracle_render_aa(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int antialias_method, uint64_t seed,
+                     int geometry_bits, int threads, float *fb_rgb, const OracleOutputs *outputs,
+                     OracleCounters *counters);
+
+void oracle_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+
+void oracle_sample_offsets(int method, uint64_t seed, uint64_t sample, uint16_t n, uint16_t p, uint16_t q, double *di,
+                           double *dj);
+
 int oracle_trace_rays(const RtScene *scene, uint64_t n, const double *origins, const double *directions,
                       const double *tmin, const double *tmax, int geometry_bits, double *t_out,
                       int32_t *shape_out, int32_t *tri_out, double *normal_out);

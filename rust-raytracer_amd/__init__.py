@@ -163,6 +163,8 @@ class RtRenderArgs(C.Structure):
         ("tile_h", C.c_uint32),
         ("part_index", C.c_uint32),
         ("part_count", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("seed", C.c_uint64),
     ]
 
 
@@ -426,19 +428,21 @@ class DeviceScene:
             pass
 
     def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-                    tile=(0, 0), part=(0, 1)) -> RtRenderArgs:
+                    tile=(0, 0), part=(0, 1), seed=0) -> RtRenderArgs:
         a = RtRenderArgs()
         a.sqrt_rays_per_pixel = int(sqrt_rays_per_pixel)
         a.antialias_method = int(antialias_method)
         a.mode = int(mode)
         a.tile_w, a.tile_h = int(tile[0]), int(tile[1])
         a.part_index, a.part_count = int(part[0]), int(part[1])
+        a.seed = int(seed)
         return a
 
     def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-               want_ids: bool = False, tile=(0, 0), part=(0, 1)):
-        """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats)."""
-        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part)
+               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0):
+        """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats).
+        `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57)."""
+        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed)
         fb = Framebuffer(self.width, self.height)
         ids = RayIds(self.width * self.height * int(sqrt_rays_per_pixel) ** 2, self.n_point_lights) if want_ids else None
         ids_struct = ids.as_struct() if ids is not None else None
@@ -493,7 +497,7 @@ class DeviceScene:
 
 
 def render(scene: Scene, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, per_pixel_cb=None,
-           device: int = 0, mode: int = RT_MODE_FAST) -> Framebuffer:
+           device: int = 0, mode: int = RT_MODE_FAST, seed: int = 0) -> Framebuffer:
     """Drop-in for raytracer_lib::render (render.rs:7-12).
 
     `per_pixel_cb` is accepted for signature parity and called once, after the
@@ -505,7 +509,7 @@ def render(scene: Scene, sqrt_rays_per_pixel: int, antialias_method=AntialiasMet
     try:
         ds = be.upload(scene)
         try:
-            fb, _, _ = ds.render(sqrt_rays_per_pixel, antialias_method, mode)
+            fb, _, _ = ds.render(sqrt_rays_per_pixel, antialias_method, mode, seed=seed)
         finally:
             ds.close()
     finally:

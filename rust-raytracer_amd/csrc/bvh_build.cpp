@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace rt {
@@ -56,6 +57,114 @@ struct Builder {
         n.axis = axis;
         combine(tree.nodes[(size_t)l].bmin, tree.nodes[(size_t)l].bmax, tree.nodes[(size_t)r].bmin,
                 tree.nodes[(size_t)r].bmax, n.bmin, n.bmax);
+        return me;
+    }
+};
+
+// Binned surface-area-heuristic builder for the fast mode's trees.  Any tree over the same
+// items gives the same closest hit; this one is built to be cheap to traverse, not to match the
+// reference's traversal order.
+struct SahBuilder {
+    std::vector<BuildItem> &items;
+    Tree &tree;
+    size_t max_leaf;
+    double node_cost = 1.0;
+
+    static double half_area(const double mn[3], const double mx[3]) {
+        const double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    void leaf(int32_t me, size_t lo, size_t hi, int inner_above) {
+        TreeNode &n = tree.nodes[(size_t)me];
+        n.first = (uint32_t)tree.order.size();
+        n.count = (uint32_t)(hi - lo);
+        for (size_t i = lo; i < hi; ++i) tree.order.push_back(items[i].id);
+        tree.inner_depth = std::max(tree.inner_depth, inner_above);
+    }
+
+    int32_t build(size_t lo, size_t hi, int inner_above) {
+        const int32_t me = (int32_t)tree.nodes.size();
+        tree.nodes.emplace_back();
+        double bmin[3], bmax[3], cmin[3], cmax[3];
+        for (int k = 0; k < 3; ++k) { bmin[k] = cmin[k] = INFINITY; bmax[k] = cmax[k] = -INFINITY; }
+        for (size_t i = lo; i < hi; ++i)
+            for (int k = 0; k < 3; ++k) {
+                bmin[k] = std::fmin(bmin[k], items[i].bmin[k]);
+                bmax[k] = std::fmax(bmax[k], items[i].bmax[k]);
+                cmin[k] = std::fmin(cmin[k], items[i].centroid[k]);
+                cmax[k] = std::fmax(cmax[k], items[i].centroid[k]);
+            }
+        std::memcpy(tree.nodes[(size_t)me].bmin, bmin, sizeof(bmin));
+        std::memcpy(tree.nodes[(size_t)me].bmax, bmax, sizeof(bmax));
+        const size_t n = hi - lo;
+        if (n <= 1) { leaf(me, lo, hi, inner_above); return me; }
+
+        constexpr int kBins = 32;
+        int best_axis = -1, best_bin = -1;
+        double best_cost = INFINITY;
+        for (int axis = 0; axis < 3; ++axis) {
+            const double ext = cmax[axis] - cmin[axis];
+            if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+            struct Bin { double mn[3], mx[3]; size_t count; } bins[kBins];
+            for (auto &b : bins) { for (int k = 0; k < 3; ++k) { b.mn[k] = INFINITY; b.mx[k] = -INFINITY; } b.count = 0; }
+            const double scale = kBins / ext;
+            for (size_t i = lo; i < hi; ++i) {
+                int b = (int)((items[i].centroid[axis] - cmin[axis]) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                bins[b].count++;
+                for (int k = 0; k < 3; ++k) {
+                    bins[b].mn[k] = std::fmin(bins[b].mn[k], items[i].bmin[k]);
+                    bins[b].mx[k] = std::fmax(bins[b].mx[k], items[i].bmax[k]);
+                }
+            }
+            double right_area[kBins];
+            size_t right_count[kBins];
+            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            size_t cnt = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                for (int k = 0; k < 3; ++k) { mn[k] = std::fmin(mn[k], bins[b].mn[k]); mx[k] = std::fmax(mx[k], bins[b].mx[k]); }
+                cnt += bins[b].count;
+                right_area[b] = cnt ? half_area(mn, mx) : 0.0;
+                right_count[b] = cnt;
+            }
+            for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+            cnt = 0;
+            for (int b = 0; b + 1 < kBins; ++b) {  // split between bin b and b + 1
+                for (int k = 0; k < 3; ++k) { mn[k] = std::fmin(mn[k], bins[b].mn[k]); mx[k] = std::fmax(mx[k], bins[b].mx[k]); }
+                cnt += bins[b].count;
+                if (cnt == 0 || right_count[b + 1] == 0) continue;
+                const double cost = half_area(mn, mx) * (double)cnt + right_area[b + 1] * (double)right_count[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        // leaf if allowed and no split is cheaper than testing the items here (node test = 1 item test)
+        if (n <= max_leaf) {
+            const double here = half_area(bmin, bmax) * (double)n;
+            if (best_axis < 0 || best_cost + node_cost * half_area(bmin, bmax) >= here) { leaf(me, lo, hi, inner_above); return me; }
+        }
+        size_t mid;
+        int axis;
+        if (best_axis >= 0) {
+            axis = best_axis;
+            const double scale = kBins / (cmax[axis] - cmin[axis]), c0 = cmin[axis];
+            const int bb = best_bin;
+            auto it = std::stable_partition(items.begin() + (long)lo, items.begin() + (long)hi, [=](const BuildItem &q) {
+                int b = (int)((q.centroid[axis] - c0) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                return b <= bb;
+            });
+            mid = (size_t)(it - items.begin());
+        } else {  // all centroids coincide: halve in the given order
+            axis = 0;
+            mid = lo + n / 2;
+        }
+        const int32_t l = build(lo, mid, inner_above + 1);
+        const int32_t r = build(mid, hi, inner_above + 1);
+        TreeNode &nd = tree.nodes[(size_t)me];
+        nd.left = l;
+        nd.right = r;
+        nd.axis = axis;
         return me;
     }
 };
@@ -217,6 +326,17 @@ void fill_payload(const RtShape &s, float f[12]) {
 
 }  // namespace
 
+Tree build_tree_sah(std::vector<BuildItem> items, size_t max_leaf) {
+    Tree tree;
+    if (items.empty()) return tree;
+    tree.nodes.reserve(items.size() * 2);
+    tree.order.reserve(items.size());
+    SahBuilder b{items, tree, max_leaf};
+    if (const char *e = std::getenv("RT_SAH_NODE")) b.node_cost = std::atof(e);
+    b.build(0, items.size(), 0);
+    return tree;
+}
+
 Tree build_tree(std::vector<BuildItem> items) {
     Tree tree;
     if (items.empty()) return tree;
@@ -268,7 +388,8 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         if (!shape_bounds(scene, s, out.blas, top[i])) return "malformed shape";
         top[i].id = (int32_t)i;
     }
-    out.tlas = build_tree(std::move(top));
+    if (const char *e = std::getenv("RT_TLAS_SAH")) out.tlas = build_tree_sah(std::move(top), (size_t)std::max(1, std::atoi(e)));
+    else out.tlas = build_tree(std::move(top));
 
     // ---- node array: scene-level tree first, then the meshes
     out.tlas_root = emit_with_header(out.tlas, 0, out.nodes);

@@ -137,46 +137,58 @@ k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_sampl
 // waves share nothing, and their run times differ widely (a wave whose rays all miss the
 // meshes is done in a few steps), so a block of four would hold its slots for the slowest
 // (measured on the bunny frame: 0.51 -> 0.39 ms camera rays, 1.08 -> 0.96 ms shadow rays).
-template <int KIND>
+// R rays per lane: lane l of block b holds work items (b * R + r) * 64 + l, r < R -- each r a run of
+// 64 consecutive samples, so loads and stores stay coalesced.
+template <int KIND, int R>
 __global__ void __launch_bounds__(RT_PACKET_BLOCK)
 k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
+    constexpr uint32_t per_block = RT_PACKET_BLOCK * R;
     const uint32_t count = KIND == 1 ? Q.counters[RT_CNT_LIT] : n_samples;
-    const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
+    const uint32_t n_blocks = (count + per_block - 1) / per_block;  // blocks that have work; the rest leave
     if (blockIdx.x >= n_blocks) return;
-    const uint32_t idx = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * (RT_BLOCK / RT_PACKET_BLOCK)) * RT_PACKET_BLOCK + threadIdx.x;
+    const uint32_t base = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * RT_BLOCK / per_block) * per_block + threadIdx.x;
     const int rows = S.stack_depth + 1;
-    FastTrav st;
-    RaySetup r;
-    uint32_t sample = 0;
-    bool live = idx < count;
-    if (live) {
-        if (KIND == 1) {
-            sample = Q.lit_list[idx];
-            live = shadow_setup_lit(S, Q, blockIdx.y, sample, r);
-        } else {
-            live = closest_setup(S, Q, B, 0, idx, r);
+    FastTrav st[R];
+    uint32_t sample[R];
+    bool live[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t idx = base + (uint32_t)k * RT_PACKET_BLOCK;
+        RaySetup r;
+        sample[k] = 0;
+        live[k] = idx < count;
+        if (live[k]) {
+            if (KIND == 1) {
+                sample[k] = Q.lit_list[idx];
+                live[k] = shadow_setup_lit(S, Q, blockIdx.y, sample[k], r);
+            } else {
+                live[k] = closest_setup(S, Q, B, 0, idx, r);
+            }
         }
+        if (!live[k]) {  // a slot without a ray: finite dummy values and an empty search interval
+            r.o = D3{0.0, 0.0, 0.0};
+            r.d = D3{0.0, 0.0, -1.0};
+            r.t0 = -__builtin_inff();
+            r.shape0 = -1;
+            r.org_shape = r.org_tri = -1;
+        }
+        fast_set_ray(st[k], (float)r.o.x, (float)r.o.y, (float)r.o.z, (float)r.d.x, (float)r.d.y, (float)r.d.z);
+        st[k].t = r.t0;
+        st[k].shape = r.shape0;
+        st[k].tri = -1;
+        st[k].org_shape = r.org_shape;
+        st[k].org_tri = r.org_tri;
     }
-    if (!live) {  // a lane without a ray: finite dummy values and an empty search interval
-        r.o = D3{0.0, 0.0, 0.0};
-        r.d = D3{0.0, 0.0, -1.0};
-        r.t0 = -__builtin_inff();
-        r.shape0 = -1;
-        r.org_shape = r.org_tri = -1;
-    }
-    fast_set_ray(st, (float)r.o.x, (float)r.o.y, (float)r.o.z, (float)r.d.x, (float)r.d.y, (float)r.d.z);
-    st.t = r.t0;
-    st.shape = r.shape0;
-    st.tri = -1;
-    st.org_shape = r.org_shape;
-    st.org_tri = r.org_tri;
     const float tmin = KIND == 1 ? (float)RT_VERY_SMALL_NUMBER : closest_tmin(0);
-    const bool ok = packet_traverse<KIND == 1>(S, st, tmin, lds + (threadIdx.x >> 6) * rows, rows - 1);
+    const bool ok = packet_traverse<KIND == 1, R>(S, st, tmin, lds, rows - 1);
     if (!ok) Q.counters[RT_CNT_OVERFLOW] = 1;
-    if (!live) return;
-    if (KIND == 1) shadow_store(Q, blockIdx.y, sample, st.shape, st.tri);
-    else closest_store(Q, idx, st.t, st.shape, st.tri);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (!live[k]) continue;
+        if (KIND == 1) shadow_store(Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
+        else closest_store(Q, base + (uint32_t)k * RT_PACKET_BLOCK, st[k].t, st[k].shape, st[k].tri);
+    }
 }
 
 // ---- compaction of the lit table into a list of sample indices, in sample order
@@ -481,10 +493,8 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
                 hipStream_t stream, RtStats *stats) {
     if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
     if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
-    if (args->antialias_method != RT_AA_NORMAL)
-        return rt::set_error(RT_ERR_UNSUPPORTED,
-                             "jittered / random antialiasing draw from an OS-seeded RNG in the reference and have "
-                             "no reproducible definition");
+    if (args->antialias_method < RT_AA_NORMAL || args->antialias_method > RT_AA_RANDOM)
+        return rt::set_error(RT_ERR_INVALID, "antialias_method must be RT_AA_NORMAL, RT_AA_JITTERED or RT_AA_RANDOM");
     const uint32_t n = args->sqrt_rays_per_pixel;
     if (n == 0 || n > 255) return rt::set_error(RT_ERR_INVALID, "sqrt_rays_per_pixel must be in 1..255");
     if (args->mode != RT_MODE_FAST && args->mode != RT_MODE_REFERENCE_ORDER)
@@ -560,7 +570,12 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     // fast mode: wave packets for camera and shadow rays (RT_PACKET=0 keeps the per-lane kernels, for comparison)
     bool use_packets = true;
     if (const char *e = std::getenv("RT_PACKET")) use_packets = std::atoi(e) != 0;
-    const size_t packet_lds = (size_t)(std::max(S.stack_depth, 1) + 1) * (RT_PACKET_BLOCK / 64) * sizeof(int32_t);
+    // rays per lane of the packet kernels.  Two (RT_PACKET_RAYS=2) halve the steps per ray but are
+    // slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays 0.88 -> 1.13 ms):
+    // the tests dominate a step, not its scalar part, and the wave needs twice the registers.
+    int packet_rays = 1;
+    if (const char *e = std::getenv("RT_PACKET_RAYS")) packet_rays = std::atoi(e) == 2 ? 2 : 1;
+    const size_t packet_lds = ((size_t)(std::max(S.stack_depth, 1) + 1) + 6u * 64u * (size_t)packet_rays) * sizeof(int32_t);
 
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
@@ -572,12 +587,14 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         B.width = W; B.height = H;
         B.n = n;
         B.compact_fb = parts > 1 ? 1u : 0u;
+        B.aa_method = args->antialias_method;
+        B.seed = args->seed;
         const uint32_t n_samples = B.n_pixels * spp;
 
         RT_HIP(hipMemsetAsync(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t), stream));
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
-        const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+        const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
         // chunk of the XCD remap, in 256-sample blocks: 128 (a few tiles) for a whole frame, smaller
         // for a small launch so that every XCD still gets >= 32 chunks -- chunks differ in cost, and
         // with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
@@ -589,8 +606,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
+            else if (bounce == 0 && use_packets && packet_rays == 2)
+                hipLaunchKernelGGL((k_trace_packet<0, 2>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
             else if (bounce == 0 && use_packets)
-                hipLaunchKernelGGL((k_trace_packet<0>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
+                hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
             else
                 hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
@@ -612,8 +631,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
                 const dim3 sg(full_grid, ds->n_point_lights);
                 if (ref_order)
                     hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
+                else if (use_packets && packet_rays == 2)
+                    hipLaunchKernelGGL((k_trace_packet<1, 2>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
                 else if (use_packets)
-                    hipLaunchKernelGGL((k_trace_packet<1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
+                    hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
                 else
                     hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
                 tm.end();

@@ -871,10 +871,51 @@ RT_HD bool self_hit_f64(const RtSceneView &S, int32_t org_shape, const D3 &o, co
 
 // ---------------------------------------------------------------- camera
 
-// antialias.rs:38-43 + camera/mod.rs:52-56 + perspective.rs:20-28 / orthographic.rs:19-26
-RT_HD void camera_ray(const RtCamera &cam, uint32_t i, uint32_t j, uint32_t p, uint32_t q, uint32_t n, D3 &o, D3 &d) {
-    const double di = ((double)p + 0.5) / (double)n;
-    const double dj = ((double)q + 0.5) / (double)n;
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11): ten rounds of two 32x32 -> 64 bit multiplications, key bumped by the Weyl constants
+// between rounds.
+RT_HD void rt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)m1;
+        c3 = (uint32_t)m0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 53 random bits -> [0, 1), like rand's Standard distribution for f64
+RT_HD double rt_unit_double(uint32_t hi, uint32_t lo) {
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// antialias.rs:26-57: offsets of sample (p, q) of pixel (i, j) inside the pixel.  `sample` is the
+// frame-wide sample index, which is the generator's counter for the two stochastic methods.
+RT_HD void sample_offsets(int32_t method, uint64_t seed, uint64_t sample, uint32_t p, uint32_t q, uint32_t n, double &di,
+                          double &dj) {
+    if (method == 0) {  // normal, antialias.rs:38-43
+        di = ((double)p + 0.5) / (double)n;
+        dj = ((double)q + 0.5) / (double)n;
+        return;
+    }
+    uint32_t x[4];
+    rt_philox4x32_10((uint32_t)sample, (uint32_t)(sample >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    const double r1 = rt_unit_double(x[0], x[1]), r2 = rt_unit_double(x[2], x[3]);
+    if (method == 1) {  // jittered, antialias.rs:45-50
+        di = ((double)p + r1) / (double)n;
+        dj = ((double)q + r2) / (double)n;
+    } else {  // random, antialias.rs:52-57
+        di = r1;
+        dj = r2;
+    }
+}
+
+// camera/mod.rs:52-56 + perspective.rs:20-28 / orthographic.rs:19-26
+RT_HD void camera_ray(const RtCamera &cam, uint32_t i, uint32_t j, double di, double dj, D3 &o, D3 &d) {
     const double u = cam.left + (cam.right - cam.left) * ((double)i + di) / (double)cam.pixels_x;
     const double v = cam.bottom + (cam.top - cam.bottom) * ((double)j + dj) / (double)cam.pixels_y;
     if (cam.type == RT_CAMERA_PERSPECTIVE) {

@@ -49,37 +49,61 @@ struct WaveStack {
 
 // Bit k set if most of the wave's live rays run towards smaller coordinates along axis k: such a
 // wave reaches a node's RIGHT child first (the builder puts the smaller centroids left).
-__device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav &s, bool live) {
-    const int half = __popcll(__ballot(live)) >> 1;
-    uint32_t bits = 0;
-    if (__popcll(__ballot(live && s.dx < 0.0f)) > half) bits |= 1u;
-    if (__popcll(__ballot(live && s.dy < 0.0f)) > half) bits |= 2u;
-    if (__popcll(__ballot(live && s.dz < 0.0f)) > half) bits |= 4u;
-    return bits;
+template <int R>
+__device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav (&s)[R], const bool (&live)[R]) {
+    int n = 0, nx = 0, ny = 0, nz = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        n += __popcll(__ballot(live[r]));
+        nx += __popcll(__ballot(live[r] && s[r].dx < 0.0f));
+        ny += __popcll(__ballot(live[r] && s[r].dy < 0.0f));
+        nz += __popcll(__ballot(live[r] && s[r].dz < 0.0f));
+    }
+    const int half = n >> 1;
+    return (nx > half ? 1u : 0u) | (ny > half ? 2u : 0u) | (nz > half ? 4u : 0u);
 }
 
-// Traverses the scene with the wave's 64 rays.  On entry `s` holds the lane's world-space ray,
-// search bound s.t (-inf for a lane without a ray), s.shape / s.tri = initial hit, and the
-// origin primitive.  Returns false on stack overflow.
-template <bool ANYHIT>
-__device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &s, float tmin, int32_t *lds_rows, int max_sp) {
+// Traverses the scene with the wave's 64 * R rays (R per lane).  On entry s[r] holds the lane's
+// r-th world-space ray, search bound s[r].t (-inf for a slot without a ray), s[r].shape / .tri =
+// initial hit, and the origin primitive.  `lds_rows`: max_sp + 1 dwords for the stack, followed
+// by 6 * R * 64 floats in which the world-space rays wait while the wave is inside an instance.
+// Returns false on stack overflow.
+//
+// R = 2 halves the number of steps per ray: the scalar work of a step (record fetch, ballots,
+// branches, stack) and the wait for the record are paid once for 128 rays, and the two
+// independent box / triangle tests of a lane interleave in the vector pipeline.
+template <bool ANYHIT, int R>
+__device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (&s)[R], float tmin, int32_t *lds_rows, int max_sp) {
     const float ninf = -__builtin_inff();
-    const float wox = s.ox, woy = s.oy, woz = s.oz, wdx = s.dx, wdy = s.dy, wdz = s.dz;
-    const bool live = s.t > ninf;
-    const uint32_t world_bits = packet_direction_bits(s, live);
+    float *world = reinterpret_cast<float *>(lds_rows + max_sp + 1) + (threadIdx.x & 63u);  // [6 * R][64]
+    bool live[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        live[r] = s[r].t > ninf;
+        world[(r * 6 + 0) * 64] = s[r].ox; world[(r * 6 + 1) * 64] = s[r].oy; world[(r * 6 + 2) * 64] = s[r].oz;
+        world[(r * 6 + 3) * 64] = s[r].dx; world[(r * 6 + 4) * 64] = s[r].dy; world[(r * 6 + 5) * 64] = s[r].dz;
+    }
+    const uint32_t world_bits = packet_direction_bits<R>(s, live);
     uint32_t dir_bits = world_bits;
     WaveStack stk;
     stk.init(lds_rows);
     bool overflow = false;  // cannot happen with the host's sizing of the stack; kept from writing outside the rows
     int32_t cur = S.tlas_root;
     int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
+    bool in_instance = false;
     for (;;) {
         while (cur >= 0) {
             const rt_f4 *n = S.nodes + (size_t)(uint32_t)cur * 4;
             const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
-            float el, er;
-            bool hl, hr;
-            fast_box2(s, a, b, c, tmin, el, er, hl, hr);  // a header's absent right child has an empty box
+            bool hl = false, hr = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float el, er;
+                bool l_in, r_in;
+                fast_box2(s[r], a, b, c, tmin, el, er, l_in, r_in);  // a header's absent right child has an empty box
+                hl = hl || l_in;
+                hr = hr || r_in;
+            }
             const bool right_first = ((dir_bits >> rt_as_int(l.z)) & 1u) != 0u;
             const int32_t ref_l = rt_as_int(l.x), ref_r = rt_as_int(l.y);
             const int32_t near = right_first ? ref_r : ref_l, far = right_first ? ref_l : ref_r;
@@ -100,8 +124,14 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
         }
         if (cur == RT_REF_NONE) break;
         if (cur == RT_REF_EXIT_BLAS) {
-            fast_set_ray(s, wox, woy, woz, wdx, wdy, wdz);
-            dir_bits = world_bits;
+            if (in_instance) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    fast_set_ray(s[r], world[(r * 6 + 0) * 64], world[(r * 6 + 1) * 64], world[(r * 6 + 2) * 64],
+                                 world[(r * 6 + 3) * 64], world[(r * 6 + 4) * 64], world[(r * 6 + 5) * 64]);
+                dir_bits = world_bits;
+                in_instance = false;
+            }
             cur_shape = -1;
             cur = stk.pop();
             continue;
@@ -112,15 +142,22 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
             for (uint32_t k = 0; k < cnt; ++k) {
                 const int32_t gtri = (int32_t)(first + k);
                 const rt_f4 *tp = S.tri_xf + (size_t)(uint32_t)gtri * 3;
-                float t;
-                const bool own = cur_shape == s.org_shape && gtri == s.org_tri;
-                if (fast_triangle(s, tp[0], tp[1], tp[2], tmin, t) && !own) {
-                    s.shape = cur_shape;
-                    s.tri = gtri;
-                    s.t = ANYHIT ? ninf : t;
+                const rt_f4 tu = tp[0], tv = tp[1], tn = tp[2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float t;
+                    const bool own = cur_shape == s[r].org_shape && gtri == s[r].org_tri;
+                    if (fast_triangle(s[r], tu, tv, tn, tmin, t) && !own) {
+                        s[r].shape = cur_shape;
+                        s[r].tri = gtri;
+                        s[r].t = ANYHIT ? ninf : t;
+                    }
                 }
             }
-            cur = (ANYHIT && __ballot(s.t > ninf) == 0ull) ? RT_REF_NONE : stk.pop();
+            bool any_left = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) any_left = any_left || s[r].t > ninf;
+            cur = (ANYHIT && __ballot(any_left) == 0ull) ? RT_REF_NONE : stk.pop();
             continue;
         }
         bool entered = false;
@@ -132,10 +169,15 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
             const bool is_inst = type == RT_SHAPE_INSTANCE;
             if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
                 if (is_inst) {
-                    // enter the instance only if some lane's ray reaches its world box
+                    // enter the instance only if some ray of the wave reaches its world box
                     const rt_f4 f0 = pp[1], f1 = pp[2];
-                    float e;
-                    if (__ballot(fast_box(s, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e)) == 0ull) continue;
+                    bool reach = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float e;
+                        reach = reach || fast_box(s[r], f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e);
+                    }
+                    if (__ballot(reach) == 0ull) continue;
                 }
                 overflow = overflow || stk.sp + 2 > max_sp;
                 stk.sp = stk.sp + 2 > max_sp ? max_sp - 2 : stk.sp;
@@ -144,36 +186,48 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav &
                 if (is_inst) {
                     const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
                     const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
-                    fast_set_ray(s, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
-                                 ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
-                                 ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
-                                 (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
-                                 (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
-                    dir_bits = packet_direction_bits(s, live);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float wox = s[r].ox, woy = s[r].oy, woz = s[r].oz, wdx = s[r].dx, wdy = s[r].dy, wdz = s[r].dz;
+                        fast_set_ray(s[r], ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
+                                     ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
+                                     ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
+                                     (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
+                                     (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+                    }
+                    dir_bits = packet_direction_bits<R>(s, live);
+                    in_instance = true;
                 }
                 cur_shape = shape_id;
                 cur = blas_root;
                 entered = true;
             } else {
-                // sphere / box / triangle at scene level, possibly instanced
-                float t;
-                bool hit;
-                if (is_inst) {
-                    FastTrav lr;
-                    fast_local_ray(S, first + k, true, wox, woy, woz, wdx, wdy, wdz, s, lr);
-                    hit = fast_payload_hit(lr, proto_type, pp[1], pp[2], pp[3], tmin, t);
-                } else {
-                    hit = fast_payload_hit(s, type, pp[1], pp[2], pp[3], tmin, t);  // s holds the world ray here
-                }
-                if (hit && shape_id != s.org_shape) {
-                    s.shape = shape_id;
-                    s.tri = -1;
-                    s.t = ANYHIT ? ninf : t;
+                // sphere / box / triangle at scene level, possibly instanced (s holds the world rays here)
+                const rt_f4 f0 = pp[1], f1 = pp[2], f2 = pp[3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float t;
+                    bool hit;
+                    if (is_inst) {
+                        FastTrav lr;
+                        fast_local_ray(S, first + k, true, s[r].ox, s[r].oy, s[r].oz, s[r].dx, s[r].dy, s[r].dz, s[r], lr);
+                        hit = fast_payload_hit(lr, proto_type, f0, f1, f2, tmin, t);
+                    } else {
+                        hit = fast_payload_hit(s[r], type, f0, f1, f2, tmin, t);
+                    }
+                    if (hit && shape_id != s[r].org_shape) {
+                        s[r].shape = shape_id;
+                        s[r].tri = -1;
+                        s[r].t = ANYHIT ? ninf : t;
+                    }
                 }
             }
         }
         if (entered) continue;
-        cur = (ANYHIT && __ballot(s.t > ninf) == 0ull) ? RT_REF_NONE : stk.pop();
+        bool any_left = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) any_left = any_left || s[r].t > ninf;
+        cur = (ANYHIT && __ballot(any_left) == 0ull) ? RT_REF_NONE : stk.pop();
     }
     return !overflow;
 }

@@ -78,6 +78,8 @@ struct RtBatch {
     uint32_t width, height;
     uint32_t n;           // sqrt_rays_per_pixel
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
+    int32_t aa_method;    // RT_AA_*
+    uint64_t seed;        // key of the sample-offset generator
 };
 
 struct RtIdOut {  // RtRayIds, device pointers (any may be null)
@@ -112,7 +114,9 @@ RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls
     uint32_t i, j;
     if (!batch_pixel(B, ls / spp, i, j)) return false;
     const uint32_t k = ls % spp;
-    camera_ray(S.camera, i, j, k / B.n, k % B.n, B.n, o, d);
+    double di, dj;
+    sample_offsets(B.aa_method, B.seed, ((uint64_t)i + (uint64_t)j * B.width) * spp + k, k / B.n, k % B.n, B.n, di, dj);
+    camera_ray(S.camera, i, j, di, dj, o, d);
     return true;
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Writes tests/golden/render_<scene>.npz: the CPU oracle's framebuffer, per-sample ids and ray
-counts for every test scene at 64x48, 4 rays per pixel, depth 6.
+counts for every test scene at 64x48, 4 rays per pixel, depth 6, and
+render_<scene>_<method>.npz for the two stochastic antialiasing methods (seed 2024) on two scenes.
 
     python3 tests/golden/make_golden.py
 
@@ -22,6 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SCENES = ["simple_sphere_scene", "spheres_and_triangles", "cornell_room", "spheres_1K", "bunny_small", "mixed_features",
           "mixed_ortho"]
 WIDTH, HEIGHT, SQRT_RPP, DEPTH = 64, 48, 2, 6
+STOCHASTIC = [("mixed_features", 1, "jittered"), ("mixed_features", 2, "random"), ("bunny_small", 1, "jittered")]
+STOCHASTIC_SEED = 2024
 
 
 def main():
@@ -37,6 +40,15 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"render_{name}.npz"), fb=fb, rays=np.array(cnt["rays"], np.int64),
                             shaded_hits=np.int64(cnt["shaded_hits"]), **arrays)
         print(name, cnt["rays"])
+    for name, method, label in STOCHASTIC:
+        sc = rt.parse_scene_file(os.path.join(ROOT, "scenes", name + ".json"), image_width=WIDTH, image_height=HEIGHT,
+                                 recursion_depth=DEPTH)
+        fb, ids, cnt = O.render(sc, SQRT_RPP, threads=1, aa=method, seed=STOCHASTIC_SEED)
+        arrays = {f: getattr(ids, f) for f in rt.ID_FIELDS}
+        np.savez_compressed(os.path.join(HERE, f"render_{name}_{label}.npz"), fb=fb, rays=np.array(cnt["rays"], np.int64),
+                            shaded_hits=np.int64(cnt["shaded_hits"]), method=np.int64(method),
+                            seed=np.int64(STOCHASTIC_SEED), **arrays)
+        print(name, label, cnt["rays"])
 
 
 if __name__ == "__main__":

@@ -161,6 +161,8 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     B.width = W; B.height = H;
     B.n = n;
     B.compact_fb = 0;  // the simulator always writes the full-image layout
+    B.aa_method = args.antialias_method;
+    B.seed = args.seed;
 
     RtIdOut io{};
     if (ids) {
@@ -389,7 +391,7 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
         if (!batch_pixel(B, (uint32_t)(ls / spp), i, j)) continue;
         const uint32_t pq = (uint32_t)(ls % spp);
         D3 o, d;
-        camera_ray(S.camera, i, j, pq / n, pq % n, n, o, d);
+        camera_ray(S.camera, i, j, ((double)(pq / n) + 0.5) / (double)n, ((double)(pq % n) + 0.5) / (double)n, o, d);
         if (light < 0) { rays.push_back(R{o, d, 1.0f, INFINITY, -1, -1, false}); continue; }
         FastTrav st; bool overflow = false;
         fast_begin(S, st, stk, o, d, INFINITY, -1, -1, -1);

@@ -52,6 +52,13 @@ def lib():
         L = C.CDLL(ORACLE_LIB)
         vp = C.c_void_p
         L.oracle_render.argtypes = [vp, C.c_uint16, C.c_int, C.c_int, vp, C.POINTER(OracleOutputs), C.POINTER(OracleCounters)]
+        L.oracle_render_aa.argtypes = [vp, C.c_uint16, C.c_int, C.c_uint64, C.c_int, C.c_int, vp, C.POINTER(OracleOutputs),
+                                       C.POINTER(OracleCounters)]
+        L.oracle_philox.argtypes = [vp, vp, vp]
+        L.oracle_philox.restype = None
+        L.oracle_sample_offsets.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint16, C.c_uint16, C.c_uint16,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.oracle_sample_offsets.restype = None
         L.oracle_trace_rays.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.oracle_point_light_count.argtypes = [vp]
         L.oracle_point_light_count.restype = C.c_uint32
@@ -70,8 +77,8 @@ def _scene_ptr(scene):
     return C.cast(scene.ptr, C.c_void_p)
 
 
-def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads: int = 0):
-    """Returns (fb [H,W,3] f32, RayIds | None, counters dict)."""
+def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads: int = 0, aa: int = 0, seed: int = 0):
+    """Returns (fb [H,W,3] f32, RayIds | None, counters dict).  aa: 0 normal, 1 jittered, 2 random."""
     W, H = scene.image_width, scene.image_height
     fb = np.zeros((H, W, 3), np.float32)
     ids = rt.RayIds(W * H * sqrt_rpp * sqrt_rpp, scene.n_point_lights) if want_ids else None
@@ -81,10 +88,10 @@ def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads:
             arr = getattr(ids, f)
             setattr(outs, f, arr.ctypes.data if arr.size else None)
     cnt = OracleCounters()
-    rc = lib().oracle_render(_scene_ptr(scene), sqrt_rpp, bits, threads, fb.ctypes.data,
-                             C.byref(outs) if ids is not None else None, C.byref(cnt))
+    rc = lib().oracle_render_aa(_scene_ptr(scene), sqrt_rpp, int(aa), int(seed), bits, threads, fb.ctypes.data,
+                                C.byref(outs) if ids is not None else None, C.byref(cnt))
     if rc != 0:
-        raise RuntimeError(f"oracle_render failed: {rc}")
+        raise RuntimeError(f"oracle_render_aa failed: {rc}")
     return fb, ids, cnt.as_dict()
 
 
@@ -104,6 +111,20 @@ def trace_rays(scene, origins, directions, tmin, tmax, bits: int = 64):
     if rc != 0:
         raise RuntimeError(f"oracle_trace_rays failed: {rc}")
     return t, shape, tri, normal
+
+
+def philox(counter, key):
+    c = np.ascontiguousarray(counter, np.uint32)
+    k = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib().oracle_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def sample_offsets(method: int, seed: int, sample: int, n: int, p: int, q: int):
+    di, dj = C.c_double(0.0), C.c_double(0.0)
+    lib().oracle_sample_offsets(method, seed, sample, n, p, q, C.byref(di), C.byref(dj))
+    return di.value, dj.value
 
 
 def _v3(a):

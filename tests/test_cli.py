@@ -77,5 +77,12 @@ def test_cli_renders_what_the_library_renders(cli, rt, backend, scene_path, tmp_
     rc, err = run(cli, "-i", scene_path("simple_sphere_scene"), "-o", out)
     assert rc == 0, err
     assert Image.open(out).size == (360, 360)
-    rc, err = run(cli, "-i", scene_path("simple_sphere_scene"), "-o", out, "--antialias-method", "jittered")
-    assert rc != 0 and "antialiasing" in err
+    # jittered sampling: reproducible with --seed, and (like the reference's thread_rng) different without
+    shots = []
+    for extra in (["--seed", "5"], ["--seed", "5"], []):
+        rc, err = run(cli, "-i", scene_path("simple_sphere_scene"), "-o", out, "-x", "96", "-y", "64",
+                      "--antialias-method", "jittered", *extra)
+        assert rc == 0, err
+        shots.append(np.asarray(Image.open(out).convert("RGB")).copy())
+    assert np.array_equal(shots[0], shots[1])
+    assert not np.array_equal(shots[0], shots[2])

@@ -41,6 +41,27 @@ def test_stage_bodies_match_oracle(rt, oracle_cache, name, mode):
     assert abs(int(stats.shadow_rays) - cnt["rays"][2]) <= max(8, cnt["rays"][2] // 5000)
 
 
+@pytest.mark.parametrize("aa", [1, 2])
+@pytest.mark.parametrize("name", ["mixed_features", "bunny_small"])
+def test_stochastic_antialiasing_matches_oracle(rt, scene_path, name, aa):
+    """Jittered / random sample offsets (antialias.rs:45-57): both sides draw the same numbers, so the
+    frames compare sample by sample like the regular grid's."""
+    sc = rt.parse_scene_file(scene_path(name), image_width=96, image_height=72, recursion_depth=6)
+    fb_o, ids_o, cnt = O.render(sc, 3, aa=aa, seed=0x1234567890ABCDEF)
+    fb, ids, stats = HS.render(sc, 3, mode=rt.RT_MODE_FAST, aa=aa, seed=0x1234567890ABCDEF)
+    parity.assert_parity(fb, ids, fb_o, ids_o, occlusion_only=True)
+    assert stats.primary_rays == cnt["rays"][0]
+    fb2, _, _ = HS.render(sc, 3, mode=rt.RT_MODE_FAST, aa=aa, seed=99, want_ids=False)
+    assert not np.array_equal(fb, fb2)
+    # the frame does not depend on how the image is tiled or split
+    whole = np.zeros_like(fb)
+    for p in range(2):
+        part, _, _ = HS.render(sc, 3, mode=rt.RT_MODE_FAST, aa=aa, seed=0x1234567890ABCDEF, want_ids=False, tile=(16, 8),
+                               part=(p, 2))
+        whole += part
+    assert np.array_equal(whole, fb)
+
+
 @pytest.mark.parametrize("name", ["mixed_features", "cornell_room"])
 def test_shadows_disabled_and_normals(rt, scene_path, name):
     for kw in ({"disable_shadows": True}, {"render_normals": True}):

@@ -206,3 +206,54 @@ def test_oracle_reproduces_committed_fixtures(rt, scene_path, name):
     for f in rt.ID_FIELDS:
         assert np.array_equal(getattr(ids, f), g[f]), f
     assert np.array_equal(fb, g["fb"])
+
+
+# ---- stochastic antialiasing (antialias.rs:45-57): the generator and the offsets' formulas
+
+def test_philox_known_answers():
+    """Philox4x32-10 known-answer vectors of the generator's authors (Random123 kat_vectors:
+    zero input, all ones, digits of pi)."""
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for counter, key, want in kat:
+        assert O.philox(counter, key).tolist() == want
+
+
+def test_sample_offsets_follow_the_reference_formulas():
+    n = 4
+    rs = []
+    for sample in range(2000):
+        p, q = (sample // n) % n, sample % n
+        x = O.philox([sample, 0, 0, 0], [77, 0])
+        r1 = float(((int(x[0]) << 32 | int(x[1])) >> 11) / 2.0 ** 53)
+        r2 = float(((int(x[2]) << 32 | int(x[3])) >> 11) / 2.0 ** 53)
+        assert 0.0 <= r1 < 1.0 and 0.0 <= r2 < 1.0
+        rs.append((r1, r2))
+        assert O.sample_offsets(0, 77, sample, n, p, q) == ((p + 0.5) / n, (q + 0.5) / n)  # antialias.rs:38-43
+        assert O.sample_offsets(1, 77, sample, n, p, q) == ((p + r1) / n, (q + r2) / n)    # antialias.rs:45-50
+        assert O.sample_offsets(2, 77, sample, n, p, q) == (r1, r2)                        # antialias.rs:52-57
+    rs = np.array(rs)
+    # uniform on the unit square: mean 1/2, variance 1/12, the two coordinates uncorrelated
+    assert np.abs(rs.mean(axis=0) - 0.5).max() < 0.02
+    assert np.abs(rs.var(axis=0) - 1.0 / 12.0).max() < 0.006
+    assert abs(np.corrcoef(rs[:, 0], rs[:, 1])[0, 1]) < 0.06
+    # another seed, another stream
+    assert O.sample_offsets(2, 78, 5, n, 1, 1) != O.sample_offsets(2, 77, 5, n, 1, 1)
+
+
+def test_stochastic_methods_converge_to_the_same_image(rt, scene_path):
+    """Jittered and random sampling estimate the same pixel integral as the regular grid: at 64
+    samples per pixel the three oracle images agree closely, and two seeds differ."""
+    sc = rt.parse_scene_file(scene_path("simple_sphere_scene"), image_width=64, image_height=48, recursion_depth=3)
+    base, _, _ = O.render(sc, 8, want_ids=False)
+    jit, _, cj = O.render(sc, 8, want_ids=False, aa=1, seed=1)
+    rnd, _, _ = O.render(sc, 8, want_ids=False, aa=2, seed=1)
+    jit2, _, _ = O.render(sc, 8, want_ids=False, aa=1, seed=2)
+    assert cj["rays"][0] == 64 * 48 * 64
+    assert not np.array_equal(jit, jit2) and not np.array_equal(jit, base)
+    assert np.abs(jit - base).mean() < 0.004 and np.abs(rnd - base).mean() < 0.012
+    assert np.abs(jit - base).mean() < np.abs(rnd - base).mean()  # stratification lowers the variance
