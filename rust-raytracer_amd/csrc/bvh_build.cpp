@@ -185,9 +185,17 @@ void box_to_f32(const double bmin[3], const double bmax[3], float omin[3], float
     }
 }
 
-void set_child_box(RtNode &rec, bool right, const double bmin[3], const double bmax[3]) {
+// `flat_pad` > 0 widens a zero extent by that much on both sides (the fast mode's own scene-level
+// tree, where a flat box must stay enterable; see flatten_scene).
+void set_child_box(RtNode &rec, bool right, const double bmin[3], const double bmax[3], double flat_pad = 0.0) {
     float lo[3], hi[3];
-    box_to_f32(bmin, bmax, lo, hi);
+    double pmin[3], pmax[3];
+    for (int k = 0; k < 3; ++k) {
+        const bool flat = flat_pad > 0.0 && !(bmin[k] < bmax[k]);
+        pmin[k] = flat ? bmin[k] - flat_pad : bmin[k];
+        pmax[k] = flat ? bmax[k] + flat_pad : bmax[k];
+    }
+    box_to_f32(pmin, pmax, lo, hi);
     float *mn = right ? rec.rmin_xy : rec.lmin_xy, *mx = right ? rec.rmax_xy : rec.lmax_xy, *z = right ? rec.rz : rec.lz;
     mn[0] = lo[0]; mn[1] = lo[1];
     mx[0] = hi[0]; mx[1] = hi[1];
@@ -222,7 +230,7 @@ void triangle_map(const double *v, RtTriXf &out) {
 
 // Emits the subtree `t` of `tree` into out.nodes and returns the reference a
 // parent stores for it.  `prim_base` is added to leaf offsets.
-int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes) {
+int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0) {
     const TreeNode &n = tree.nodes[(size_t)t];
     if (n.count > 0) return rt_make_leaf_ref(prim_base + n.first, n.count);
     const int32_t me = (int32_t)nodes.size();
@@ -230,11 +238,11 @@ int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode
     const TreeNode &l = tree.nodes[(size_t)n.left];
     const TreeNode &r = tree.nodes[(size_t)n.right];
     RtNode rec{};
-    set_child_box(rec, false, l.bmin, l.bmax);
-    set_child_box(rec, true, r.bmin, r.bmax);
+    set_child_box(rec, false, l.bmin, l.bmax, flat_pad);
+    set_child_box(rec, true, r.bmin, r.bmax, flat_pad);
     nodes[(size_t)me] = rec;
-    const int32_t lref = emit(tree, n.left, prim_base, nodes);
-    const int32_t rref = emit(tree, n.right, prim_base, nodes);
+    const int32_t lref = emit(tree, n.left, prim_base, nodes, flat_pad);
+    const int32_t rref = emit(tree, n.right, prim_base, nodes, flat_pad);
     nodes[(size_t)me].left = lref;
     nodes[(size_t)me].right = rref;
     nodes[(size_t)me].axis = n.axis;
@@ -243,18 +251,18 @@ int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode
 
 // Header node: its left child is the tree's root (with the root's own box, which
 // the reference tests on entry, bvh.rs:95), its right child is absent.
-int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNode> &nodes) {
+int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0) {
     const int32_t header = (int32_t)nodes.size();
     nodes.emplace_back();
     RtNode rec{};
-    set_child_box(rec, false, tree.nodes[0].bmin, tree.nodes[0].bmax);
+    set_child_box(rec, false, tree.nodes[0].bmin, tree.nodes[0].bmax, flat_pad);
     // the absent right child is a box of zero extent: entry == exit on every axis, so no ray enters
     // it under any form of the slab test (an inverted +-inf box would pass a min/max test)
     rec.rmin_xy[0] = rec.rmin_xy[1] = rec.rz[0] = 0.0f;
     rec.rmax_xy[0] = rec.rmax_xy[1] = rec.rz[1] = 0.0f;
     rec.right = RT_REF_NONE;
     nodes[(size_t)header] = rec;
-    const int32_t root_ref = emit(tree, 0, prim_base, nodes);
+    const int32_t root_ref = emit(tree, 0, prim_base, nodes, flat_pad);
     nodes[(size_t)header].left = root_ref;
     return header;
 }
@@ -388,11 +396,42 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         if (!shape_bounds(scene, s, out.blas, top[i])) return "malformed shape";
         top[i].id = (int32_t)i;
     }
-    if (const char *e = std::getenv("RT_TLAS_SAH")) out.tlas = build_tree_sah(std::move(top), (size_t)std::max(1, std::atoi(e)));
-    else out.tlas = build_tree(std::move(top));
+    out.tlas = build_tree(top);
+
+    // ---- the fast mode's own scene-level tree.  The closest hit does not depend on the tree, with
+    // one exception that the reference's tree does decide: a box of zero thickness is never entered
+    // (bbox.rs:89,104,119), so the shapes of a reference LEAF whose box is flat are invisible (a lone
+    // axis-aligned triangle, say), while the same shape sharing a leaf with others is visible.  The
+    // fast tree therefore holds exactly the shapes the reference can reach, its own flat boxes are
+    // widened so that they can be entered, and within that it is free to split by surface area,
+    // which suits shapes of very different sizes better than the median split does.
+    std::vector<BuildItem> reachable;
+    double scene_min[3] = {INFINITY, INFINITY, INFINITY}, scene_max[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const TreeNode &n : out.tlas.nodes) {
+        if (n.count == 0) continue;
+        if (!(n.bmin[0] < n.bmax[0]) || !(n.bmin[1] < n.bmax[1]) || !(n.bmin[2] < n.bmax[2])) continue;
+        for (uint32_t k = 0; k < n.count; ++k) {
+            const BuildItem &it = top[(size_t)out.tlas.order[n.first + k]];
+            reachable.push_back(it);
+            for (int c = 0; c < 3; ++c) {
+                if (std::isfinite(it.bmin[c])) scene_min[c] = std::fmin(scene_min[c], it.bmin[c]);
+                if (std::isfinite(it.bmax[c])) scene_max[c] = std::fmax(scene_max[c], it.bmax[c]);
+            }
+        }
+    }
+    double flat_pad = 0.0;
+    for (int c = 0; c < 3; ++c)
+        if (scene_min[c] <= scene_max[c])
+            flat_pad = std::fmax(flat_pad, std::fmax(scene_max[c] - scene_min[c], std::fmax(std::fabs(scene_min[c]), std::fabs(scene_max[c]))));
+    flat_pad = flat_pad > 0.0 ? flat_pad * 1e-5 : 1e-5;
+    std::sort(reachable.begin(), reachable.end(), [](const BuildItem &a, const BuildItem &b) { return a.id < b.id; });
+    const bool own_fast_tree = !reachable.empty();
+    if (own_fast_tree) out.tlas_fast = build_tree_sah(std::move(reachable), 2);
 
     // ---- node array: scene-level tree first, then the meshes
     out.tlas_root = emit_with_header(out.tlas, 0, out.nodes);
+    const uint32_t fast_base = (uint32_t)out.tlas.order.size();  // the fast tree's primitives follow the reference tree's
+    out.tlas_root_fast = own_fast_tree ? emit_with_header(out.tlas_fast, fast_base, out.nodes, flat_pad) : out.tlas_root;
     std::vector<int32_t> blas_root(scene.n_meshes);
     int blas_depth = 0;
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
@@ -401,7 +440,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
     }
     // pushes on one path: one per inner node with two live children, plus, when a
     // mesh or instance is entered from a leaf, the rest of that leaf and the exit marker
-    out.stack_depth = out.tlas.inner_depth + 2 + blas_depth + 1;
+    out.stack_depth = std::max(out.tlas.inner_depth, out.tlas_fast.inner_depth) + 2 + blas_depth + 1;
 
     // ---- triangles in leaf order
     out.tris.resize((size_t)tri_total);
@@ -434,11 +473,12 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         }
     }
 
-    // ---- top-level primitives in leaf order
-    out.tprims.resize(out.tlas.order.size());
-    out.tprim_xf.assign(out.tlas.order.size() * 12, 0.0f);
-    for (size_t k = 0; k < out.tlas.order.size(); ++k) {
-        const int32_t id = out.tlas.order[k];
+    // ---- top-level primitives in leaf order: the reference tree's, then the fast tree's
+    const size_t n_tprims = out.tlas.order.size() + out.tlas_fast.order.size();
+    out.tprims.resize(n_tprims);
+    out.tprim_xf.assign(n_tprims * 12, 0.0f);
+    for (size_t k = 0; k < n_tprims; ++k) {
+        const int32_t id = k < out.tlas.order.size() ? out.tlas.order[k] : out.tlas_fast.order[k - out.tlas.order.size()];
         const RtShape &s = scene.shapes[id];
         RtTPrim &p = out.tprims[k];
         std::memset(&p, 0, sizeof(p));

@@ -32,6 +32,10 @@ struct Tree {
 // BVHNode::new (geometry/bvh.rs:36-87) starting on the X axis (bvh.rs:136).
 Tree build_tree(std::vector<BuildItem> items);
 
+// Binned surface-area-heuristic tree with at most `max_leaf` items per leaf (not the reference's
+// tree: only for traversal that does not depend on the reference's visiting order).
+Tree build_tree_sah(std::vector<BuildItem> items, size_t max_leaf);
+
 struct FlatScene {
     std::vector<RtNode> nodes;
     std::vector<RtTPrim> tprims;
@@ -42,8 +46,11 @@ struct FlatScene {
     std::vector<double> verts64;          // 12 doubles per triangle, same order as `tris`: a, b, c and the
                                           // unit normal Triangle::new stores (triangle.rs:22)
     int32_t tlas_root = 0;                // header node of the scene-level tree
+    int32_t tlas_root_fast = 0;           // header node of the fast mode's scene-level tree (its leaves index
+                                          // the second part of `tprims`)
     int stack_depth = 0;                  // traversal-stack entries a ray can need at most
     Tree tlas;                            // kept for structural tests
+    Tree tlas_fast;
     std::vector<Tree> blas;
 };
 

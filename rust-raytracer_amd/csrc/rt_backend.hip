@@ -372,7 +372,8 @@ struct RtBackend {
 struct RtDeviceScene {
     RtBackend *backend = nullptr;  // identity check only; may already be destroyed when the scene is freed
     int device = 0;
-    RtSceneView view{};
+    RtSceneView view{};       // reference-order mode: the reference's scene-level tree
+    RtSceneView view_fast{};  // fast mode: the same arrays, entered through the fast mode's scene-level tree
     std::vector<void *> allocs;
     uint32_t width = 0, height = 0;
     uint32_t n_point_lights = 0;
@@ -539,7 +540,7 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     int rc = ensure_buffers(be, capacity, ds->n_point_lights);
     if (rc) return rc;
     const RtBuffers Q = be->buf;
-    const RtSceneView &S = ds->view;
+    const RtSceneView &S = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view : ds->view_fast;
 
     RtIdOut io{};
     if (ids) {
@@ -789,6 +790,8 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
     V.recursion_depth = scene->recursion_depth;
     V.disable_shadows = scene->disable_shadows;
     V.stack_depth = flat.stack_depth;
+    ds->view_fast = V;
+    ds->view_fast.tlas_root = flat.tlas_root_fast;
     ds->width = scene->image_width;
     ds->height = scene->image_height;
     ds->n_point_lights = (uint32_t)point_lights.size();
@@ -1032,7 +1035,7 @@ extern "C" int rt_trace_rays(RtBackend *be, const RtDeviceScene *ds, uint64_t n,
     if (mode == RT_MODE_REFERENCE_ORDER)
         hipLaunchKernelGGL((k_trace_user<false, true>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
     else
-        hipLaunchKernelGGL((k_trace_user<true, false>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
+        hipLaunchKernelGGL((k_trace_user<true, false>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view_fast, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
     uint32_t over = 0;
     if (hipStreamSynchronize(be->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
         hipMemcpy(t_out, d_t, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||

@@ -59,7 +59,7 @@ struct VecStack {
 struct HostScene {
     rt::FlatScene flat;
     std::vector<int32_t> point_lights;
-    RtSceneView view{};
+    RtSceneView view{}, view_fast{};  // reference-order / fast mode (different scene-level trees)
     bool has_mirror = false, has_lit = false;
 };
 
@@ -89,6 +89,8 @@ std::string make_view(const RtScene &scene, HostScene &hs) {
     V.recursion_depth = scene.recursion_depth;
     V.disable_shadows = scene.disable_shadows;
     V.stack_depth = hs.flat.stack_depth;
+    hs.view_fast = V;
+    hs.view_fast.tlas_root = hs.flat.tlas_root_fast;
     for (uint32_t s = 0; s < scene.n_shapes; ++s) {
         const int32_t t = scene.shaders[scene.shapes[s].shader].type;
         hs.has_mirror = hs.has_mirror || t == RT_SHADER_PERFECT_MIRROR;
@@ -106,7 +108,7 @@ T *grab(std::vector<std::vector<char>> &pool, size_t count) {
 template <bool ORDERED, bool ANYHIT, bool EXACT>
 void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, float *fb, const RtRayIds *ids,
          RtStats *stats) {
-    const RtSceneView &S = hs.view;
+    const RtSceneView &S = EXACT ? hs.view : hs.view_fast;
     const uint32_t n = args.sqrt_rays_per_pixel, spp = n * n;
     const uint32_t W = scene.image_width, H = scene.image_height;
     const uint32_t tw = args.tile_w ? args.tile_w : 32, th = args.tile_h ? args.tile_h : 32;
@@ -326,9 +328,9 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
             ok = traverse<VecStack, false, false, true>(hs.view, ray, (float)tmin[r], hit, os, ot, stk, hs.view.stack_depth);
         else {
             FastTrav st;
-            fast_begin(hs.view, st, stk, ro, rd, hit.t, hit.shape, os, ot);
+            fast_begin(hs.view_fast, st, stk, ro, rd, hit.t, hit.shape, os, ot);
             bool overflow = false;
-            while (fast_step<VecStack, false>(hs.view, st, stk, (float)tmin[r], hs.view.stack_depth, overflow)) {
+            while (fast_step<VecStack, false>(hs.view_fast, st, stk, (float)tmin[r], hs.view_fast.stack_depth, overflow)) {
             }
             ok = !overflow;
             hit.t = st.t;
@@ -344,13 +346,14 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
 }
 
 // Structure of the flattened trees, for comparison with the oracle's own build:
-// which = -1 scene-level, else mesh index.  Same conventions as oracle_bvh_dump.
+// which = -1 scene-level (reference order), -2 the fast mode's scene-level tree, else mesh index.
+// Same conventions as oracle_bvh_dump.
 extern "C" int64_t hostsim_bvh_dump(const RtScene *scene, int32_t which, int64_t cap_nodes, int64_t cap_prims,
                                     int32_t *kinds_out, int32_t *prims_out, double *boxes_out, int64_t *n_prims_out,
                                     int32_t *stack_depth_out) {
     rt::FlatScene flat;
     if (!rt::flatten_scene(*scene, flat).empty()) return -2;
-    const rt::Tree &t = which < 0 ? flat.tlas : flat.blas[(size_t)which];
+    const rt::Tree &t = which == -2 ? flat.tlas_fast : (which < 0 ? flat.tlas : flat.blas[(size_t)which]);
     if ((int64_t)t.nodes.size() > cap_nodes || (int64_t)t.order.size() > cap_prims) return -1;
     for (size_t i = 0; i < t.nodes.size(); ++i) {
         kinds_out[i] = t.nodes[i].count ? (int32_t)t.nodes[i].count : -1;
@@ -370,7 +373,7 @@ extern "C" int64_t hostsim_bvh_dump(const RtScene *scene, int32_t which, int64_t
 extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args, int light, double *out) {
     HostScene hs;
     if (!make_view(*scene, hs).empty()) return -1;
-    const RtSceneView &S = hs.view;
+    const RtSceneView &S = hs.view_fast;
     const uint32_t n = args->sqrt_rays_per_pixel, spp = n * n;
     const uint32_t W = scene->image_width, H = scene->image_height;
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;

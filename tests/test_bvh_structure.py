@@ -77,7 +77,38 @@ def test_stack_depth_bounds_the_walk(rt, scene_path):
 
         sys.setrecursionlimit(10000)
         k_top, _, _, stack_depth = HS.bvh_dump(sc, -1)
-        need = depth_of(k_top)
+        k_fast, _, _, _ = HS.bvh_dump(sc, -2)  # the fast mode's own scene-level tree
+        need = max(depth_of(k_top), depth_of(k_fast))
         mesh = max([depth_of(HS.bvh_dump(sc, m)[0]) for m in range(sc.c.n_meshes)] or [0])
         assert stack_depth >= need + mesh + 1
         assert stack_depth <= need + mesh + 6  # and is not wastefully large (LDS stack rows)
+
+
+def test_fast_scene_tree_holds_the_reachable_shapes(rt, scene_path, tmp_path):
+    """The fast mode's scene-level tree is split by surface area, not by the reference's median rule, so
+    it must hold exactly the shapes the reference's tree can reach: all of them, except those in a
+    reference leaf whose box has zero thickness (never entered, bbox.rs:89,104,119)."""
+    for name in ["spheres_1K", "mixed_features", "cornell_room", "spheres_and_triangles"]:
+        sc = rt.parse_scene_file(scene_path(name))
+        kinds, prims, boxes, _ = HS.bvh_dump(sc, -1)
+        reachable, at = [], 0
+        for k, b in zip(kinds.tolist(), boxes):
+            if k < 0:
+                continue
+            if (b[3:] > b[:3]).all():
+                reachable += prims[at:at + k].tolist()
+            at += k
+        k_fast, p_fast, b_fast, _ = HS.bvh_dump(sc, -2)
+        assert sorted(p_fast.tolist()) == sorted(reachable), name
+        assert max(k for k in k_fast.tolist() if k > 0) <= 2
+        # every node's box contains its children's boxes (pre-order: left child follows its parent)
+        def check(i):
+            if k_fast[i] >= 0:
+                return i + 1
+            l = i + 1
+            r = check(l)
+            end = check(r)
+            for c in (l, r):
+                assert (b_fast[c][:3] >= b_fast[i][:3]).all() and (b_fast[c][3:] <= b_fast[i][3:]).all()
+            return end
+        assert check(0) == len(k_fast)
