@@ -196,9 +196,9 @@ void set_child_box(RtNode &rec, bool right, const double bmin[3], const double b
         pmax[k] = flat ? bmax[k] + flat_pad : bmax[k];
     }
     box_to_f32(pmin, pmax, lo, hi);
-    float *mn = right ? rec.rmin_xy : rec.lmin_xy, *mx = right ? rec.rmax_xy : rec.lmax_xy, *z = right ? rec.rz : rec.lz;
-    mn[0] = lo[0]; mn[1] = lo[1];
-    mx[0] = hi[0]; mx[1] = hi[1];
+    float *x = right ? rec.rx : rec.lx, *y = right ? rec.ry : rec.ly, *z = right ? rec.rz : rec.lz;
+    x[0] = lo[0]; x[1] = hi[0];
+    y[0] = lo[1]; y[1] = hi[1];
     z[0] = lo[2]; z[1] = hi[2];
 }
 
@@ -246,7 +246,8 @@ int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode
     nodes[(size_t)me].left = lref;
     nodes[(size_t)me].right = rref;
     nodes[(size_t)me].axis = n.axis;
-    return me;
+    nodes[(size_t)me].right_first_mask = n.axis == 0 ? 0xAA : (n.axis == 1 ? 0xCC : 0xF0);
+    return me * (int32_t)sizeof(RtNode);
 }
 
 // Header node: its left child is the tree's root (with the root's own box, which
@@ -258,13 +259,12 @@ int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNod
     set_child_box(rec, false, tree.nodes[0].bmin, tree.nodes[0].bmax, flat_pad);
     // the absent right child is a box of zero extent: entry == exit on every axis, so no ray enters
     // it under any form of the slab test (an inverted +-inf box would pass a min/max test)
-    rec.rmin_xy[0] = rec.rmin_xy[1] = rec.rz[0] = 0.0f;
-    rec.rmax_xy[0] = rec.rmax_xy[1] = rec.rz[1] = 0.0f;
+    rec.rx[0] = rec.rx[1] = rec.ry[0] = rec.ry[1] = rec.rz[0] = rec.rz[1] = 0.0f;
     rec.right = RT_REF_NONE;
     nodes[(size_t)header] = rec;
     const int32_t root_ref = emit(tree, 0, prim_base, nodes, flat_pad);
     nodes[(size_t)header].left = root_ref;
-    return header;
+    return header * (int32_t)sizeof(RtNode);
 }
 
 void set3(double dst[3], const RtVec3 &v) {
@@ -440,6 +440,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
     }
     // pushes on one path: one per inner node with two live children, plus, when a
     // mesh or instance is entered from a leaf, the rest of that leaf and the exit marker
+    if (out.nodes.size() >= (1u << 25)) return "too many tree nodes for a 31-bit byte offset";
     out.stack_depth = std::max(out.tlas.inner_depth, out.tlas_fast.inner_depth) + 2 + blas_depth + 1;
 
     // ---- triangles in leaf order

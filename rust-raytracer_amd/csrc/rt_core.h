@@ -446,14 +446,14 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
     for (;;) {
         while (cur >= 0) {
             RT_TALLY(node);
-            const rt_f4 *n = S.nodes + (size_t)cur * 4;
+            const rt_f4 *n = reinterpret_cast<const rt_f4 *>(reinterpret_cast<const char *>(S.nodes) + (uint32_t)cur);
             const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
             const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
             float el = 0.0f, er = 0.0f;
-            // RtNode: a = left (min.x, min.y, max.x, max.y), b = right likewise, c = z planes (l min, l max, r min, r max)
-            const bool hl = slab_f32<EXACT>(a.x, a.y, c.x, a.z, a.w, c.y, ray, tmin, hit.t, el);
+            // RtNode: a = left (min.x, max.x, min.y, max.y), b = right likewise, c = z planes (l min, l max, r min, r max)
+            const bool hl = slab_f32<EXACT>(a.x, a.z, c.x, a.y, a.w, c.y, ray, tmin, hit.t, el);
             const bool hr =
-                rref != RT_REF_NONE && slab_f32<EXACT>(b.x, b.y, c.z, b.z, b.w, c.w, ray, tmin, hit.t, er);
+                rref != RT_REF_NONE && slab_f32<EXACT>(b.x, b.z, c.z, b.y, b.w, c.w, ray, tmin, hit.t, er);
             if (hl && hr) {
                 const bool swap = ORDERED && er < el;
                 if (sp >= max_sp) return false;
@@ -651,17 +651,38 @@ RT_HD bool fast_box(const FastTrav &s, float mnx, float mny, float mnz, float mx
     return e < x;
 }
 
-// Both child boxes of a node at once (see rt_f2 above).
+// Both child boxes of a node at once (see rt_f2 above): a = left (min.x, max.x, min.y, max.y),
+// b = right likewise, c = (left min.z, max.z, right min.z, max.z).
 RT_HD void fast_box2(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, const rt_f4 &c, float tmin, float &el, float &er,
                      bool &hl, bool &hr) {
-    const rt_f2 ixy = s.ixy, nxy = s.nxy, izz = rt_lo2(s.zin), nzz = rt_hi2(s.zin);
-    const rt_f2 l0 = rt_fma2(rt_pair(a.x, a.y), ixy, nxy), l1 = rt_fma2(rt_pair(a.z, a.w), ixy, nxy);
-    const rt_f2 r0 = rt_fma2(rt_pair(b.x, b.y), ixy, nxy), r1 = rt_fma2(rt_pair(b.z, b.w), ixy, nxy);
+    const rt_f2 ixx = rt_lo2(s.ixy), nxx = rt_lo2(s.nxy), iyy = rt_hi2(s.ixy), nyy = rt_hi2(s.nxy);
+    const rt_f2 izz = rt_lo2(s.zin), nzz = rt_hi2(s.zin);
+    const rt_f2 lx = rt_fma2(rt_pair(a.x, a.y), ixx, nxx), ly = rt_fma2(rt_pair(a.z, a.w), iyy, nyy);
+    const rt_f2 rx = rt_fma2(rt_pair(b.x, b.y), ixx, nxx), ry = rt_fma2(rt_pair(b.z, b.w), iyy, nyy);
     const rt_f2 lz = rt_fma2(rt_pair(c.x, c.y), izz, nzz), rz = rt_fma2(rt_pair(c.z, c.w), izz, nzz);
-    el = rt_fmax(rt_fmax(rt_fmax(rt_fmin(l0.x, l1.x), rt_fmin(l0.y, l1.y)), rt_fmin(lz.x, lz.y)), tmin);
-    const float xl = rt_fmin(rt_fmin(rt_fmin(rt_fmax(l0.x, l1.x), rt_fmax(l0.y, l1.y)), rt_fmax(lz.x, lz.y)), s.t);
-    er = rt_fmax(rt_fmax(rt_fmax(rt_fmin(r0.x, r1.x), rt_fmin(r0.y, r1.y)), rt_fmin(rz.x, rz.y)), tmin);
-    const float xr = rt_fmin(rt_fmin(rt_fmin(rt_fmax(r0.x, r1.x), rt_fmax(r0.y, r1.y)), rt_fmax(rz.x, rz.y)), s.t);
+    el = rt_fmax(rt_fmax(rt_fmax(rt_fmin(lx.x, lx.y), rt_fmin(ly.x, ly.y)), rt_fmin(lz.x, lz.y)), tmin);
+    const float xl = rt_fmin(rt_fmin(rt_fmin(rt_fmax(lx.x, lx.y), rt_fmax(ly.x, ly.y)), rt_fmax(lz.x, lz.y)), s.t);
+    er = rt_fmax(rt_fmax(rt_fmax(rt_fmin(rx.x, rx.y), rt_fmin(ry.x, ry.y)), rt_fmin(rz.x, rz.y)), tmin);
+    const float xr = rt_fmin(rt_fmin(rt_fmin(rt_fmax(rx.x, rx.y), rt_fmax(ry.x, ry.y)), rt_fmax(rz.x, rz.y)), s.t);
+    hl = el < xl;
+    hr = er < xr;
+}
+
+// The same for a ray whose direction signs are known at compile time: OCT bit k set = the ray runs
+// towards smaller coordinates on axis k (its 1/d there is negative), so it enters a slab through
+// the max plane -- the second element of the pair -- and leaves through the min plane.
+template <int OCT>
+RT_HD void fast_box2_signed(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, const rt_f4 &c, float tmin, bool &hl, bool &hr) {
+    const rt_f2 ixx = rt_lo2(s.ixy), nxx = rt_lo2(s.nxy), iyy = rt_hi2(s.ixy), nyy = rt_hi2(s.nxy);
+    const rt_f2 izz = rt_lo2(s.zin), nzz = rt_hi2(s.zin);
+    const rt_f2 lx = rt_fma2(rt_pair(a.x, a.y), ixx, nxx), ly = rt_fma2(rt_pair(a.z, a.w), iyy, nyy);
+    const rt_f2 rx = rt_fma2(rt_pair(b.x, b.y), ixx, nxx), ry = rt_fma2(rt_pair(b.z, b.w), iyy, nyy);
+    const rt_f2 lz = rt_fma2(rt_pair(c.x, c.y), izz, nzz), rz = rt_fma2(rt_pair(c.z, c.w), izz, nzz);
+    constexpr bool nx = (OCT & 1) != 0, ny = (OCT & 2) != 0, nz = (OCT & 4) != 0;
+    const float el = rt_fmax(rt_fmax(rt_fmax(nx ? lx.y : lx.x, ny ? ly.y : ly.x), nz ? lz.y : lz.x), tmin);
+    const float xl = rt_fmin(rt_fmin(rt_fmin(nx ? lx.x : lx.y, ny ? ly.x : ly.y), nz ? lz.x : lz.y), s.t);
+    const float er = rt_fmax(rt_fmax(rt_fmax(nx ? rx.y : rx.x, ny ? ry.y : ry.x), nz ? rz.y : rz.x), tmin);
+    const float xr = rt_fmin(rt_fmin(rt_fmin(nx ? rx.x : rx.y, ny ? ry.x : ry.y), nz ? rz.x : rz.y), s.t);
     hl = el < xl;
     hr = er < xr;
 }
@@ -753,8 +774,8 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
     while (cur >= 0) {
         RT_TALLY(node);
         RT_VISIT(0, cur);
-        const rt_f4 *n = reinterpret_cast<const rt_f4 *>(node_base + ((uint32_t)cur << 6));
-        // a = left (min.x, min.y, max.x, max.y), b = right likewise, c = z planes (l min, l max, r min, r max)
+        const rt_f4 *n = reinterpret_cast<const rt_f4 *>(node_base + (uint32_t)cur);
+        // a = left (min.x, max.x, min.y, max.y), b = right likewise, c = z planes (l min, l max, r min, r max)
         const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
         const int32_t lref = rt_as_int(l.x), rref = rt_as_int(l.y);
         float el, er;

@@ -10,24 +10,27 @@
 // differs from its Box<BVHNode> pointers.
 //
 // Child reference encoding:
-//   ref >= 0                inner node index into the node array
+//   ref >= 0                inner node: BYTE offset of its record in the node array (index * 64),
+//                           which a scalar load takes as its offset operand without arithmetic
 //   ref <  0, != NONE       leaf: v = ~ref, count = v & 7 (1..4), first = v >> 3
 //                           (first indexes the top-level primitive table, or the
 //                           triangle table while inside a mesh)
 //   ref == RT_REF_NONE      no child (only in a tree's header node)
 //
-// Plane order: the x and y planes of both boxes come first, in (min.x, min.y) / (max.x, max.y)
-// pairs, the four z planes last.  A ray then needs its (1/d.x, 1/d.y) pair for the first four
-// register pairs of the record and 1/d.z for the last two, which is the operand shape of the
-// packed fp32 multiply-add (two planes per instruction).
+// Plane order: per box and axis one (min, max) pair.  The packed fp32 multiply-add turns such a
+// pair into the ray's two plane distances on that axis in one instruction, and for a ray whose
+// direction sign on the axis is known the first or second of the two IS the entry distance: no
+// min / max needed to sort them.
 struct RtNode {
-    float lmin_xy[2], lmax_xy[2];
-    float rmin_xy[2], rmax_xy[2];
-    float lz[2];  // left box min.z, max.z
-    float rz[2];  // right box min.z, max.z
+    float lx[2], ly[2];  // left box: (min.x, max.x), (min.y, max.y)
+    float rx[2], ry[2];  // right box
+    float lz[2];         // left box (min.z, max.z)
+    float rz[2];         // right box (min.z, max.z)
     int32_t left, right;
+    // bit o set: a ray of direction octant o (bit k of o = it runs towards smaller coordinates on
+    // axis k) comes to the RIGHT child first, i.e. (o >> axis) & 1
+    int32_t right_first_mask;
     int32_t axis;  // the axis the two children were split on: the left child holds the smaller centroids
-    int32_t _pad;
 };
 static_assert(sizeof(RtNode) == 64, "RtNode must be 64 bytes");
 

@@ -30,11 +30,13 @@
 struct WaveStack {
     int32_t *base;
     int32_t sp;
-    int32_t tos;  // same in all lanes
-    __device__ __forceinline__ void init(int32_t *b) { base = b; sp = 0; tos = RT_REF_NONE; }
+    int32_t high;  // most entries ever held: checked against the rows once, at the end
+    int32_t tos;   // same in all lanes
+    __device__ __forceinline__ void init(int32_t *b) { base = b; sp = 0; high = 0; tos = RT_REF_NONE; }
     __device__ __forceinline__ void push(int32_t ref) {
         base[sp] = tos;  // all lanes store the same value to the same address
         sp += 1;
+        high = high > sp ? high : sp;
         tos = ref;
     }
     // Row 0 holds the RT_REF_NONE moved there by the first push; popping an empty stack
@@ -47,20 +49,77 @@ struct WaveStack {
     }
 };
 
-// Bit k set if most of the wave's live rays run towards smaller coordinates along axis k: such a
-// wave reaches a node's RIGHT child first (the builder puts the smaller centroids left).
+// Direction signs of the wave's live rays.  Bits 0..2: bit k set if most of them run towards smaller
+// coordinates along axis k (such a wave reaches a node's RIGHT child first: the builder puts the
+// smaller centroids left).  Bit 3: the rays do NOT all agree on all three axes.  "Runs towards
+// smaller coordinates" is read off the clamped 1/d the box test multiplies with, so that it is
+// also defined for d = +-0.
 template <int R>
 __device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav (&s)[R], const bool (&live)[R]) {
     int n = 0, nx = 0, ny = 0, nz = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         n += __popcll(__ballot(live[r]));
-        nx += __popcll(__ballot(live[r] && s[r].dx < 0.0f));
-        ny += __popcll(__ballot(live[r] && s[r].dy < 0.0f));
-        nz += __popcll(__ballot(live[r] && s[r].dz < 0.0f));
+        nx += __popcll(__ballot(live[r] && s[r].ixy.x < 0.0f));
+        ny += __popcll(__ballot(live[r] && s[r].ixy.y < 0.0f));
+        nz += __popcll(__ballot(live[r] && s[r].zin.x < 0.0f));
     }
     const int half = n >> 1;
-    return (nx > half ? 1u : 0u) | (ny > half ? 2u : 0u) | (nz > half ? 4u : 0u);
+    const bool mixed = (nx != 0 && nx != n) || (ny != 0 && ny != n) || (nz != 0 && nz != n);
+    return (nx > half ? 1u : 0u) | (ny > half ? 2u : 0u) | (nz > half ? 4u : 0u) | (mixed ? 8u : 0u);
+}
+
+// Inner nodes until a leaf (or the end) comes up.  OCT 0..7: all live rays of the wave have these
+// direction signs (bit k = negative on axis k), which turns the twelve min / max that sort each
+// slab's two plane distances into register choices made at compile time; OCT 8: mixed signs, the
+// general test.
+template <int OCT, int R>
+__device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastTrav (&s)[R], float tmin, WaveStack &stk, int32_t cur,
+                                               uint32_t dir_bits) {
+    const char *node_base = reinterpret_cast<const char *>(S.nodes);
+    while (cur >= 0) {
+        const rt_f4 *n = reinterpret_cast<const rt_f4 *>(node_base + (uint32_t)cur);
+        const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
+        bool hl = false, hr = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool l_in, r_in;  // a header's absent right child has an empty box
+            if (OCT < 8) {
+                fast_box2_signed<OCT & 7>(s[r], a, b, c, tmin, l_in, r_in);
+            } else {
+                float el, er;
+                fast_box2(s[r], a, b, c, tmin, el, er, l_in, r_in);
+            }
+            hl = hl || l_in;
+            hr = hr || r_in;
+        }
+        const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+        const int32_t ref_l = rt_as_int(l.x), ref_r = rt_as_int(l.y);
+        const uint32_t order = (uint32_t)rt_as_int(l.z);  // RtNode::right_first_mask
+        const bool right_first = ((order >> (OCT < 8 ? (uint32_t)OCT : (dir_bits & 7u))) & 1u) != 0u;
+        // two mirrored copies instead of selecting near / far operands: the branch is one scalar
+        // instruction, the selects were six
+        if (right_first) {
+            if (mr != 0ull) {
+                if (ml != 0ull) stk.push(ref_l);
+                cur = ref_r;
+            } else if (ml != 0ull) {
+                cur = ref_l;
+            } else {
+                cur = stk.pop();
+            }
+        } else {
+            if (ml != 0ull) {
+                if (mr != 0ull) stk.push(ref_r);
+                cur = ref_l;
+            } else if (mr != 0ull) {
+                cur = ref_r;
+            } else {
+                cur = stk.pop();
+            }
+        }
+    }
+    return cur;
 }
 
 // Traverses the scene with the wave's 64 * R rays (R per lane).  On entry s[r] holds the lane's
@@ -87,39 +146,21 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
     uint32_t dir_bits = world_bits;
     WaveStack stk;
     stk.init(lds_rows);
-    bool overflow = false;  // cannot happen with the host's sizing of the stack; kept from writing outside the rows
     int32_t cur = S.tlas_root;
     int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
     bool in_instance = false;
     for (;;) {
-        while (cur >= 0) {
-            const rt_f4 *n = S.nodes + (size_t)(uint32_t)cur * 4;
-            const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
-            bool hl = false, hr = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float el, er;
-                bool l_in, r_in;
-                fast_box2(s[r], a, b, c, tmin, el, er, l_in, r_in);  // a header's absent right child has an empty box
-                hl = hl || l_in;
-                hr = hr || r_in;
-            }
-            const bool right_first = ((dir_bits >> rt_as_int(l.z)) & 1u) != 0u;
-            const int32_t ref_l = rt_as_int(l.x), ref_r = rt_as_int(l.y);
-            const int32_t near = right_first ? ref_r : ref_l, far = right_first ? ref_l : ref_r;
-            const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
-            const bool any_near = (right_first ? mr : ml) != 0ull, any_far = (right_first ? ml : mr) != 0ull;
-            if (any_near) {
-                if (any_far) {
-                    overflow = overflow || stk.sp >= max_sp;
-                    stk.sp = stk.sp >= max_sp ? max_sp - 1 : stk.sp;
-                    stk.push(far);
-                }
-                cur = near;
-            } else if (any_far) {
-                cur = far;
-            } else {
-                cur = stk.pop();
+        if (cur >= 0) {
+            switch (dir_bits) {
+            case 0: cur = packet_walk<0, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 1: cur = packet_walk<1, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 2: cur = packet_walk<2, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 3: cur = packet_walk<3, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 4: cur = packet_walk<4, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 5: cur = packet_walk<5, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 6: cur = packet_walk<6, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 7: cur = packet_walk<7, R>(S, s, tmin, stk, cur, dir_bits); break;
+            default: cur = packet_walk<8, R>(S, s, tmin, stk, cur, dir_bits); break;
             }
         }
         if (cur == RT_REF_NONE) break;
@@ -179,8 +220,6 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                     }
                     if (__ballot(reach) == 0ull) continue;
                 }
-                overflow = overflow || stk.sp + 2 > max_sp;
-                stk.sp = stk.sp + 2 > max_sp ? max_sp - 2 : stk.sp;
                 if (k + 1 < cnt) stk.push(rt_make_leaf_ref(first + k + 1, cnt - k - 1));
                 stk.push(RT_REF_EXIT_BLAS);
                 if (is_inst) {
@@ -229,5 +268,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
         for (int r = 0; r < R; ++r) any_left = any_left || s[r].t > ninf;
         cur = (ANYHIT && __ballot(any_left) == 0ull) ? RT_REF_NONE : stk.pop();
     }
-    return !overflow;
+    // The host sizes the rows for the deepest path, so this cannot fail; if it ever did, the surplus
+    // entries have overwritten the world rays stored behind the rows and the frame is reported as failed.
+    return stk.high <= max_sp;
 }
