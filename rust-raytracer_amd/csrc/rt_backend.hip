@@ -26,6 +26,17 @@
 #include "rt_error.h"
 #include "rt_pipeline.h"
 #include "rt_packet.h"
+// Register budgets (waves per SIMD the compiler must make room for; 512 VGPRs / waves).  These
+// kernels wait on memory most of the time, so one more resident wave is worth more than the
+// handful of values that get spilled for it -- as long as the spills stay out of the loops:
+//   packets   8 waves (64 VGPRs, 36..48 B of scratch in the scene-level primitive code): bunny frame
+//             camera rays 0.326 -> 0.312 ms, shadow rays 0.794 -> 0.736 ms; 7 waves lies in between
+//   shade     4 waves (127 VGPRs, no scratch; 131 without the hint, which is 3 waves): 0.342 -> 0.310 ms;
+//             5 waves spill 108 B inside the f64 code: 0.49 ms
+//   accumulate 8 waves (60 VGPRs, no scratch; 76 without the hint): 0.195 -> 0.183 ms
+#define RT_PACKET_WAVES 8
+#define RT_SHADE_WAVES 4
+#define RT_ACC_WAVES 8
 
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
@@ -96,7 +107,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuf
         trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, B, bounce, idx, stk);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce, uint32_t n_samples) {
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES))) k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce, uint32_t n_samples) {
     const uint32_t count = bounce == 0 ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < count; base += gridDim.x * RT_BLOCK) {
         const uint32_t idx = base + threadIdx.x;
@@ -140,7 +151,7 @@ k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_sampl
 // R rays per lane: lane l of block b holds work items (b * R + r) * 64 + l, r < R -- each r a run of
 // 64 consecutive samples, so loads and stores stay coalesced.
 template <int KIND, int R>
-__global__ void __launch_bounds__(RT_PACKET_BLOCK)
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
 k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
     constexpr uint32_t per_block = RT_PACKET_BLOCK * R;
@@ -254,7 +265,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(RtSceneView S, RtBuff
     trace_shadow_body<LdsStack, ORDERED, ANYHIT, EXACT>(S, Q, blockIdx.y, Q.lit_list[e], stk);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids) {
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_ACC_WAVES, RT_ACC_WAVES))) k_accumulate(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids) {
     const uint32_t n_lit = Q.counters[RT_CNT_LIT];
     const uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (e >= n_lit) return;
@@ -571,11 +582,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     // fast mode: wave packets for camera and shadow rays (RT_PACKET=0 keeps the per-lane kernels, for comparison)
     bool use_packets = true;
     if (const char *e = std::getenv("RT_PACKET")) use_packets = std::atoi(e) != 0;
-    // rays per lane of the packet kernels.  Two (RT_PACKET_RAYS=2) halve the steps per ray but are
-    // slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays 0.88 -> 1.13 ms):
-    // the tests dominate a step, not its scalar part, and the wave needs twice the registers.
-    int packet_rays = 1;
-    if (const char *e = std::getenv("RT_PACKET_RAYS")) packet_rays = std::atoi(e) == 2 ? 2 : 1;
+    // One ray per lane in the packet kernels.  Two per lane (the template's R) halve the steps per
+    // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
+    // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
+    constexpr int packet_rays = 1;
     const size_t packet_lds = ((size_t)(std::max(S.stack_depth, 1) + 1) + 6u * 64u * (size_t)packet_rays) * sizeof(int32_t);
 
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
@@ -607,8 +617,6 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
-            else if (bounce == 0 && use_packets && packet_rays == 2)
-                hipLaunchKernelGGL((k_trace_packet<0, 2>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
             else if (bounce == 0 && use_packets)
                 hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
             else
@@ -632,8 +640,6 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
                 const dim3 sg(full_grid, ds->n_point_lights);
                 if (ref_order)
                     hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
-                else if (use_packets && packet_rays == 2)
-                    hipLaunchKernelGGL((k_trace_packet<1, 2>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
                 else if (use_packets)
                     hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
                 else
