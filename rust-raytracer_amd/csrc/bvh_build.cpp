@@ -210,22 +210,28 @@ void triangle_map(const double *v, RtTriXf &out) {
     const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
     const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
     if (!(nn > 0.0) || !std::isfinite(nn)) {
-        for (int k = 0; k < 4; ++k) out.u[k] = out.v[k] = out.n[k] = NAN;
+        for (int k = 0; k < 8; ++k) out.uv[k] = NAN;
+        for (int k = 0; k < 4; ++k) out.n[k] = NAN;
         return;
     }
     // rows of [e1 e2 n]^-1:  (e2 x n)/nn,  (n x e1)/nn,  n/nn
     const double ru[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
     const double rv[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
     const double rn[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
+    float u[4], w[4];
     for (int k = 0; k < 3; ++k) {
-        out.u[k] = (float)ru[k];
-        out.v[k] = (float)rv[k];
+        u[k] = (float)ru[k];
+        w[k] = (float)rv[k];
         out.n[k] = (float)rn[k];
     }
     // offsets from the ROUNDED rows, so that the map is exact at vertex a for the fp32 rows
-    out.u[3] = (float)-((double)out.u[0] * a[0] + (double)out.u[1] * a[1] + (double)out.u[2] * a[2]);
-    out.v[3] = (float)-((double)out.v[0] * a[0] + (double)out.v[1] * a[1] + (double)out.v[2] * a[2]);
+    u[3] = (float)-((double)u[0] * a[0] + (double)u[1] * a[1] + (double)u[2] * a[2]);
+    w[3] = (float)-((double)w[0] * a[0] + (double)w[1] * a[1] + (double)w[2] * a[2]);
     out.n[3] = (float)-((double)out.n[0] * a[0] + (double)out.n[1] * a[1] + (double)out.n[2] * a[2]);
+    for (int k = 0; k < 4; ++k) {
+        out.uv[2 * k] = u[k];
+        out.uv[2 * k + 1] = w[k];
+    }
 }
 
 // Emits the subtree `t` of `tree` into out.nodes and returns the reference a
@@ -366,7 +372,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         if (mesh.n_triangles == 0 || !mesh.vertices) return "mesh without triangles";
         out.mesh_tri_base.push_back(tri_total);
         tri_total += mesh.n_triangles;
-        if (tri_total >= (1ull << 28)) return "too many mesh triangles for the 28-bit leaf offset";
+        if (tri_total >= (1ull << 26)) return "too many mesh triangles (their records are addressed by 32-bit byte offsets)";
         std::vector<BuildItem> items((size_t)mesh.n_triangles);
         for (uint64_t i = 0; i < mesh.n_triangles; ++i) {
             const double *v = mesh.vertices + i * 9;

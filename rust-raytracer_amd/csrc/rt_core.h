@@ -557,12 +557,14 @@ RT_HD float rt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 typedef float rt_f2 __attribute__((ext_vector_type(2)));
 RT_HD rt_f2 rt_fma2(rt_f2 a, rt_f2 b, rt_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 RT_HD rt_f2 rt_pair(float x, float y) { return rt_f2{x, y}; }
+RT_HD rt_f2 rt_mul2(rt_f2 a, rt_f2 b) { return a * b; }
 RT_HD rt_f2 rt_lo2(rt_f2 v) { return __builtin_shufflevector(v, v, 0, 0); }
 RT_HD rt_f2 rt_hi2(rt_f2 v) { return __builtin_shufflevector(v, v, 1, 1); }
 #else
 struct rt_f2 { float x, y; };
 RT_HD rt_f2 rt_fma2(rt_f2 a, rt_f2 b, rt_f2 c) { return rt_f2{rt_fma(a.x, b.x, c.x), rt_fma(a.y, b.y, c.y)}; }
 RT_HD rt_f2 rt_pair(float x, float y) { return rt_f2{x, y}; }
+RT_HD rt_f2 rt_mul2(rt_f2 a, rt_f2 b) { return rt_f2{a.x * b.x, a.y * b.y}; }
 RT_HD rt_f2 rt_lo2(rt_f2 v) { return rt_f2{v.x, v.x}; }
 RT_HD rt_f2 rt_hi2(rt_f2 v) { return rt_f2{v.y, v.y}; }
 #endif
@@ -691,17 +693,23 @@ RT_HD void fast_box2_signed(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, c
 // t from the height row, then beta and gamma of the point at t.  Same acceptance rules:
 // t in [tmin, bound] closed, gamma in [0, 1], beta in [0, 1 - gamma]; a ray parallel to the
 // plane gives t = inf or NaN and fails the range test, as |det A| < epsilon does there.
-RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &u, const rt_f4 &v, const rt_f4 &n, float tmin, float &t_out) {
+//
+// uv0 = (u.x, v.x, u.y, v.y), uv1 = (u.z, v.z, u.w, v.w) (RtTriXf::uv), n = the height row.  gamma <= 1
+// needs no test of its own: beta >= 0 and beta <= 1 - gamma imply it (1 - gamma is exact near 1).
+RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &uv0, const rt_f4 &uv1, const rt_f4 &n, float tmin, float &t_out) {
     const float hn = rt_fma(n.x, s.ox, rt_fma(n.y, s.oy, rt_fma(n.z, s.oz, n.w)));
     const float dn = rt_fma(n.x, s.dx, rt_fma(n.y, s.dy, n.z * s.dz));
     const float t = -hn * rt_rcp_approx(dn);
     if (!(t >= tmin && t <= s.t)) return false;
-    const float ou = rt_fma(u.x, s.ox, rt_fma(u.y, s.oy, rt_fma(u.z, s.oz, u.w)));
-    const float du = rt_fma(u.x, s.dx, rt_fma(u.y, s.dy, u.z * s.dz));
-    const float ov = rt_fma(v.x, s.ox, rt_fma(v.y, s.oy, rt_fma(v.z, s.oz, v.w)));
-    const float dv = rt_fma(v.x, s.dx, rt_fma(v.y, s.dy, v.z * s.dz));
-    const float beta = rt_fma(t, du, ou), gamma = rt_fma(t, dv, ov);
-    if (!(gamma >= 0.0f && gamma <= 1.0f)) return false;
+    // (beta, gamma) of the origin and their rates of change along the ray, both at once
+    const rt_f2 o2 = rt_fma2(rt_pair(uv0.x, uv0.y), rt_pair(s.ox, s.ox),
+                             rt_fma2(rt_pair(uv0.z, uv0.w), rt_pair(s.oy, s.oy),
+                                     rt_fma2(rt_pair(uv1.x, uv1.y), rt_pair(s.oz, s.oz), rt_pair(uv1.z, uv1.w))));
+    const rt_f2 d2 = rt_fma2(rt_pair(uv0.x, uv0.y), rt_pair(s.dx, s.dx),
+                             rt_fma2(rt_pair(uv0.z, uv0.w), rt_pair(s.dy, s.dy), rt_mul2(rt_pair(uv1.x, uv1.y), rt_pair(s.dz, s.dz))));
+    const rt_f2 bg = rt_fma2(rt_pair(t, t), d2, o2);
+    const float beta = bg.x, gamma = bg.y;
+    if (!(gamma >= 0.0f)) return false;
     if (!(beta >= 0.0f && beta <= 1.0f - gamma)) return false;
     t_out = t;
     return true;

@@ -111,8 +111,11 @@ static_assert(sizeof(RtTPrim) == 64, "RtTPrim must be 64 bytes");
 // are its coordinates in the frame (b - a, c - a, (b - a) x (c - a)) at a, i.e. the solution of
 // triangle.rs:76-105's linear system without the per-ray determinants.  A degenerate
 // triangle (the reference's det A == 0, never hit) stores NaN rows.
+// The beta and gamma rows are stored interleaved, (u.x, v.x), (u.y, v.y), (u.z, v.z), (u.w, v.w): each
+// pair is one operand of a packed multiply-add that advances both barycentrics at once.
 struct RtTriXf {
-    float u[4], v[4], n[4];
+    float uv[8];
+    float n[4];
 };
 static_assert(sizeof(RtTriXf) == 48, "RtTriXf must be 48 bytes");
 

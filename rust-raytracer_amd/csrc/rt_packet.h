@@ -180,15 +180,20 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
         const uint32_t v = (uint32_t)~cur;
         const uint32_t cnt = v & 7u, first = v >> 3;
         if (cur_shape >= 0) {
-            for (uint32_t k = 0; k < cnt; ++k) {
+            // the triangle a lane's ray starts on, if it belongs to this mesh (it is skipped)
+            int32_t own_tri[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) own_tri[r] = cur_shape == s[r].org_shape ? s[r].org_tri : -1;
+            const char *tri_base = reinterpret_cast<const char *>(S.tri_xf);
+            uint32_t at = first * (uint32_t)sizeof(RtTriXf);
+            for (uint32_t k = 0; k < cnt; ++k, at += (uint32_t)sizeof(RtTriXf)) {
                 const int32_t gtri = (int32_t)(first + k);
-                const rt_f4 *tp = S.tri_xf + (size_t)(uint32_t)gtri * 3;
-                const rt_f4 tu = tp[0], tv = tp[1], tn = tp[2];
+                const rt_f4 *tp = reinterpret_cast<const rt_f4 *>(tri_base + at);
+                const rt_f4 uv0 = tp[0], uv1 = tp[1], tn = tp[2];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float t;
-                    const bool own = cur_shape == s[r].org_shape && gtri == s[r].org_tri;
-                    if (fast_triangle(s[r], tu, tv, tn, tmin, t) && !own) {
+                    if (fast_triangle(s[r], uv0, uv1, tn, tmin, t) && gtri != own_tri[r]) {
                         s[r].shape = cur_shape;
                         s[r].tri = gtri;
                         s[r].t = ANYHIT ? ninf : t;
