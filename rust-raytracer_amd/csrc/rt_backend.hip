@@ -203,26 +203,46 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
 }
 
 // ---- compaction of the lit table into a list of sample indices, in sample order
-// (count per 1024-sample block -> exclusive scan of the block counts -> scatter).  Large blocks
+// (count per 1024-sample chunk -> exclusive scan of the chunk counts -> scatter).  Large chunks
 // keep the single-block scan in the middle short: it is pure latency on the frame's critical path.
 // No global atomics: thousands of waves adding to one counter serialise on it.
+//
+// A chunk is worked on by a 256-thread block in four rounds of 256 consecutive samples.  Blocks
+// of 1024 threads need sixteen free wave slots on ONE compute unit at once; with several frames
+// in flight the packet kernels of the other frames (one-wave blocks, eight per SIMD) rarely
+// leave that many, and these small kernels -- which every frame waits for -- sat in the queue
+// for hundreds of microseconds.
 
-__global__ void __launch_bounds__(RT_LIT_BLOCK) k_lit_count(RtBuffers Q, uint32_t n_samples) {
-    const uint32_t s = blockIdx.x * RT_LIT_BLOCK + threadIdx.x;
-    const int n = __syncthreads_count(s < n_samples && Q.l_shape[s] >= 0 ? 1 : 0);
-    if (threadIdx.x == 0) Q.block_counts[blockIdx.x] = (uint32_t)n;
+#define RT_LIT_THREADS 256
+#define RT_LIT_ROUNDS (RT_LIT_BLOCK / RT_LIT_THREADS)
+
+__global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_count(RtBuffers Q, uint32_t n_samples) {
+    int mine = 0;
+    for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
+        const uint32_t s = blockIdx.x * RT_LIT_BLOCK + r * RT_LIT_THREADS + threadIdx.x;
+        mine += s < n_samples && Q.l_shape[s] >= 0 ? 1 : 0;
+    }
+    __shared__ int wave_sum[RT_LIT_THREADS / 64];
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < RT_LIT_THREADS / 64; ++w) n += wave_sum[w];
+        Q.block_counts[blockIdx.x] = (uint32_t)n;
+    }
 }
 
 // One block: block_counts[0..n_blocks) -> exclusive prefix sums in place, total -> counters[RT_CNT_LIT].
-__global__ void __launch_bounds__(1024) k_lit_scan(RtBuffers Q, uint32_t n_blocks) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (n_blocks + 1023u) / 1024u;
+__global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scan(RtBuffers Q, uint32_t n_blocks) {
+    __shared__ uint32_t part[RT_LIT_THREADS];
+    const uint32_t per = (n_blocks + RT_LIT_THREADS - 1u) / RT_LIT_THREADS;
     const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_blocks);
     uint32_t acc = 0;
     for (uint32_t b = lo; b < hi; ++b) acc += Q.block_counts[b];
     part[threadIdx.x] = acc;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele inclusive scan
+    for (uint32_t d = 1; d < RT_LIT_THREADS; d <<= 1) {  // Hillis-Steele inclusive scan
         const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
         __syncthreads();
         part[threadIdx.x] += v;
@@ -234,21 +254,30 @@ __global__ void __launch_bounds__(1024) k_lit_scan(RtBuffers Q, uint32_t n_block
         Q.block_counts[b] = run;
         run += c;
     }
-    if (threadIdx.x == 1023) Q.counters[RT_CNT_LIT] = part[1023];
+    if (threadIdx.x == RT_LIT_THREADS - 1) Q.counters[RT_CNT_LIT] = part[RT_LIT_THREADS - 1];
 }
 
-__global__ void __launch_bounds__(RT_LIT_BLOCK) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
-    __shared__ uint32_t wave_total[RT_LIT_BLOCK / 64];
-    const uint32_t s = blockIdx.x * RT_LIT_BLOCK + threadIdx.x;
-    const bool lit = s < n_samples && Q.l_shape[s] >= 0;
-    const unsigned long long mask = __ballot(lit);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+__global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
+    __shared__ uint32_t wave_total[RT_LIT_ROUNDS][RT_LIT_THREADS / 64];
     const uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    bool lit[RT_LIT_ROUNDS];
+    uint32_t rank[RT_LIT_ROUNDS];
+    for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
+        const uint32_t s = blockIdx.x * RT_LIT_BLOCK + r * RT_LIT_THREADS + threadIdx.x;
+        lit[r] = s < n_samples && Q.l_shape[s] >= 0;
+        const unsigned long long mask = __ballot(lit[r]);
+        rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if ((threadIdx.x & 63u) == 0) wave_total[r][wave] = (uint32_t)__popcll(mask);
+    }
     __syncthreads();
+    // samples of a chunk are ordered round by round, wave by wave inside a round
     uint32_t off = Q.block_counts[blockIdx.x];
-    for (uint32_t w = 0; w < wave; ++w) off += wave_total[w];
-    if (lit) Q.lit_list[off + rank] = s;
+    for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
+        for (uint32_t w = 0; w < RT_LIT_THREADS / 64; ++w) {
+            if (w == wave && lit[r]) Q.lit_list[off + rank[r]] = blockIdx.x * RT_LIT_BLOCK + r * RT_LIT_THREADS + threadIdx.x;
+            off += wave_total[r][w];
+        }
+    }
 }
 
 // Work item = (point light blockIdx.y, lit entry): consecutive lanes are neighbouring
@@ -629,9 +658,9 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         if (ds->has_lit) {
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             const uint32_t lit_grid = (n_samples + RT_LIT_BLOCK - 1) / RT_LIT_BLOCK;
-            hipLaunchKernelGGL(k_lit_count, dim3(lit_grid), dim3(RT_LIT_BLOCK), 0, stream, Q, n_samples);
-            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(1024), 0, stream, Q, lit_grid);
-            hipLaunchKernelGGL(k_lit_scatter, dim3(lit_grid), dim3(RT_LIT_BLOCK), 0, stream, Q, n_samples);
+            hipLaunchKernelGGL(k_lit_count, dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
+            hipLaunchKernelGGL(k_lit_scatter, dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
             tm.end();
             // the number of lit hits is only known on the device: size the grids for the worst
             // case, surplus blocks return at once
