@@ -173,6 +173,41 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
     dev.close()
 
 
+def test_frames_in_flight_on_several_backends(rt, backend, scene_path):
+    """Four backends on one GPU, each with its own stream, render different frames at the same time
+    with no host synchronisation in between (what the benchmark does).  Every frame must equal the
+    one a single backend renders alone: the frames share nothing but the GPU."""
+    import torch
+
+    W, H = 320, 200
+    jobs = [("cornell_room", 3, 0, 0), ("mixed_features", 2, 1, 11), ("bunny_small", 3, 0, 0), ("spheres_1K", 2, 2, 5)]
+    scenes = [rt.parse_scene_file(scene_path(n), image_width=W, image_height=H, recursion_depth=6) for n, _, _, _ in jobs]
+    alone = []
+    for sc, (_, n, aa, seed) in zip(scenes, jobs):
+        dev = backend.upload(sc)
+        fb, _, _ = dev.render(n, antialias_method=aa, seed=seed)
+        alone.append(fb.pixels.copy())
+        dev.close()
+    backends = [rt.Backend(0) for _ in jobs]
+    devs = [b.upload(sc) for b, sc in zip(backends, scenes)]
+    streams = [torch.cuda.Stream() for _ in jobs]
+    rounds = 6
+    out = [[torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") for _ in range(rounds)] for _ in jobs]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for k, (_, n, aa, seed) in enumerate(jobs):
+            a = devs[k].render_args(n, antialias_method=aa, seed=seed)
+            devs[k].render_device(a, out[k][r].data_ptr(), stream=streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(len(jobs)):
+        for r in range(rounds):
+            assert np.array_equal(out[k][r].cpu().numpy().reshape(H, W, 3), alone[k]), (jobs[k][0], r)
+    for d in devs:
+        d.close()
+    for b in backends:
+        b.close()
+
+
 def test_trace_rays_matches_oracle(rt, backend, scene_path):
     """rt_trace_rays (BVH::closest_hit, geometry/bvh.rs:140) on rays that are not camera rays."""
     scene = rt.parse_scene_file(scene_path("mixed_features"))
