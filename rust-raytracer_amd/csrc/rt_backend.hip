@@ -629,6 +629,9 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         B.compact_fb = parts > 1 ? 1u : 0u;
         B.aa_method = args->antialias_method;
         B.seed = args->seed;
+        rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
+        if (const char *e = std::getenv("RT_PIXEL_BLOCK"))  // 0 = plain row-major order, for comparison
+            if (std::atoi(e) == 0) B.blk_w_log2 = B.blk_h_log2 = 0;
         const uint32_t n_samples = B.n_pixels * spp;
 
         RT_HIP(hipMemsetAsync(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t), stream));

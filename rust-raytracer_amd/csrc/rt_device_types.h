@@ -91,6 +91,17 @@ inline uint32_t rt_tile_skew(uint32_t tiles_x, uint32_t tiles_y, uint32_t parts)
     return best;
 }
 
+// Pixel block of the in-tile order (RtBatch::blk_*_log2): the power-of-two block, as square as
+// possible (wider than high if not), that holds about 64 samples and divides the tile.
+inline void rt_pixel_block(uint32_t tile_w, uint32_t tile_h, uint32_t samples_per_pixel, uint32_t &w_log2, uint32_t &h_log2) {
+    uint32_t px_log2 = 0;
+    while ((2u << px_log2) * samples_per_pixel <= 96u) ++px_log2;  // 9 samples per pixel: 8 pixels, 4 x 2
+    w_log2 = (px_log2 + 1) / 2;
+    h_log2 = px_log2 / 2;
+    while (w_log2 > 0 && tile_w % (1u << w_log2) != 0) --w_log2;
+    while (h_log2 > 0 && tile_h % (1u << h_log2) != 0) --h_log2;
+}
+
 // Top-level primitive, 64 bytes, stored in leaf order of the scene-level tree.
 //   SPHERE    f[0..2] center, f[3] radius
 //   BOX       f[0..2] min, f[3..5] max

@@ -80,6 +80,12 @@ struct RtBatch {
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
     int32_t aa_method;    // RT_AA_*
     uint64_t seed;        // key of the sample-offset generator
+    // Order of the pixels inside a tile: in blocks of (1 << blk_w_log2) x (1 << blk_h_log2) pixels,
+    // row-major inside a block and from block to block.  The host picks the block so that it holds
+    // about 64 samples: the 64 consecutive samples of a wavefront then cover a compact patch of the
+    // image instead of a strip one pixel high, and the nodes their rays visit overlap more.
+    // 0 / 0 = plain row-major order.
+    uint32_t blk_w_log2, blk_h_log2;
 };
 
 struct RtIdOut {  // RtRayIds, device pointers (any may be null)
@@ -90,8 +96,13 @@ RT_HD bool batch_pixel(const RtBatch &B, uint32_t lp, uint32_t &i, uint32_t &j) 
     const uint32_t tp = B.tile_w * B.tile_h;
     const uint32_t slot = B.slot0 + lp / tp, r = lp % tp;
     const uint32_t tile = (uint32_t)B.tile_list[slot];
-    i = (tile % B.tiles_x) * B.tile_w + r % B.tile_w;
-    j = (tile / B.tiles_x) * B.tile_h + r / B.tile_w;
+    const uint32_t bshift = B.blk_w_log2 + B.blk_h_log2;
+    const uint32_t blk = r >> bshift, in_blk = r & ((1u << bshift) - 1u);
+    const uint32_t blocks_per_row = B.tile_w >> B.blk_w_log2;
+    const uint32_t x = ((blk % blocks_per_row) << B.blk_w_log2) + (in_blk & ((1u << B.blk_w_log2) - 1u));
+    const uint32_t y = ((blk / blocks_per_row) << B.blk_h_log2) + (in_blk >> B.blk_w_log2);
+    i = (tile % B.tiles_x) * B.tile_w + x;
+    j = (tile / B.tiles_x) * B.tile_h + y;
     return i < B.width && j < B.height;
 }
 
@@ -448,8 +459,8 @@ RT_HD void resolve_body(const RtBuffers &Q, const RtBatch &B, uint32_t lp, float
     const float div = (float)(uint16_t)(B.n * B.n);
     float *px;
     if (B.compact_fb) {
-        const uint32_t tp = B.tile_w * B.tile_h;
-        px = fb + ((size_t)(B.slot0 + lp / tp) * tp + lp % tp) * 3;
+        const uint32_t tp = B.tile_w * B.tile_h;  // tiles are stored row-major whatever the order they were worked in
+        px = fb + ((size_t)(B.slot0 + lp / tp) * tp + (size_t)(j % B.tile_h) * B.tile_w + i % B.tile_w) * 3;
     } else {
         px = fb + ((size_t)i + (size_t)j * B.width) * 3;
     }

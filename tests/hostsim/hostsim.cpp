@@ -165,6 +165,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     B.compact_fb = 0;  // the simulator always writes the full-image layout
     B.aa_method = args.antialias_method;
     B.seed = args.seed;
+    rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
 
     RtIdOut io{};
     if (ids) {
@@ -384,6 +385,7 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
     B.tile_list = tile_list.data();
     B.n_pixels = (uint32_t)tile_list.size() * tw * th;
     B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x; B.width = W; B.height = H; B.n = n;
+    if (!std::getenv("RT_PIXEL_BLOCK") || std::atoi(std::getenv("RT_PIXEL_BLOCK")) != 0) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
     const long n_samples = (long)B.n_pixels * spp;
     // rays: camera rays, or shadow rays from the camera rays' hit points
     struct R { D3 o, d; float tmin, tmax; int32_t os, ot; bool anyhit; };

@@ -133,7 +133,13 @@ def test_batched_render_equals_single_batch(rt, backend, scene_path):
     assert s_many.kernel_launches[rt.KERNEL_CLASSES.index("resolve")] > s_one.kernel_launches[rt.KERNEL_CLASSES.index("resolve")]
     assert np.array_equal(one.pixels, many.pixels)
     for f in rt.ID_FIELDS:
-        assert np.array_equal(getattr(ids_one, f), getattr(ids_many, f)), f
+        a, b = getattr(ids_one, f), getattr(ids_many, f)
+        if f.startswith("shadow"):
+            # fast mode stops at the first blocker it meets, and which one that is depends on the rays
+            # that share the wavefront (batches cut the list of lit samples differently): only
+            # "no ray / visible / blocked" is defined
+            a, b = np.minimum(a, 0), np.minimum(b, 0)
+        assert np.array_equal(a, b), f
     assert s_one.total_rays() == s_many.total_rays()
     dev.close()
 
