@@ -53,8 +53,8 @@ def measured_traffic(workload, kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
     command (profiles/pmc_traffic.json, written by tools/summarize_pmc.py), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    want = {"trace_shadow": ("k_trace_packet<1>", "k_trace_fast<1>", "k_trace_shadow"),
-            "trace_closest": ("k_trace_packet<0>", "k_trace_fast<0>", "k_trace_closest")}.get(kernel_class, ())
+    want = {"trace_shadow": ("k_trace_packet<1,", "k_trace_fast<1>", "k_trace_shadow"),
+            "trace_closest": ("k_trace_packet<0,", "k_trace_fast<0>", "k_trace_closest")}.get(kernel_class, ())
     try:
         with open(path) as f:
             entry = json.load(f).get(workload)
@@ -299,10 +299,12 @@ def main():
         if frame_check:
             out["config"]["frame_check"] = frame_check
         if world == 1 and not args.no_cpu_baseline:
-            sample_px = 700 if args.workload.startswith("bunny") else 500
+            # one frame of the benchmarked workload itself on one core (the reference's loop is serial,
+            # render.rs:36-50): about 9 s for the bunny frame; the 4K workload is sampled at 1000x1000
+            sample_px = 1000
             v1, dt1 = cpu_baseline(rt, scene_name, depth, sample_px, 3, 1)
             out["cpu_baseline"] = {"value": v1, "unit": "rays/s", "cores": 1, "kind": "port",
-                                   "sample": f"same scene at {sample_px}x{sample_px} rpp9 depth{depth}, "
+                                   "sample": f"one frame of the same scene at {sample_px}x{sample_px} rpp9 depth{depth}, "
                                              f"C++ restatement of the reference (not the Rust build), {dt1:.1f} s"}
             cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             vN, dtN = cpu_baseline(rt, scene_name, depth, 1000, 3, cores)
