@@ -132,6 +132,15 @@ typedef struct RtRenderArgs {
     uint32_t part_index, part_count;
     uint32_t reserved0;           /* 0 */
     uint64_t seed;                /* key of the sample-offset generator (JITTERED / RANDOM) */
+    /* render.rs:11, 80-82: the reference calls per_pixel_cb once for every finished pixel, on the
+     * calling thread (the CLI advances a progress bar with it, main.rs:86-100).  A frame here
+     * finishes in batches of tiles, so the callback gets counts instead: NULL, or a function that
+     * a BLOCKING render (rt_render; rt_render_device with stats_out) calls on the calling thread
+     * after every finished batch with the pixels of this part finished so far and their total.
+     * The last call has pixels_done == pixels_total.  Never called by a render that only
+     * enqueues. */
+    void (*progress)(uint64_t pixels_done, uint64_t pixels_total, void *user);
+    void *progress_user;
 } RtRenderArgs;
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is

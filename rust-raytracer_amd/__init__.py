@@ -153,6 +153,10 @@ class RtParseArgs(C.Structure):
     ]
 
 
+# void (*progress)(uint64_t pixels_done, uint64_t pixels_total, void *user)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint64, C.c_uint64, C.c_void_p)
+
+
 class RtRenderArgs(C.Structure):
     _fields_ = [
         ("sqrt_rays_per_pixel", C.c_uint16),
@@ -165,6 +169,8 @@ class RtRenderArgs(C.Structure):
         ("part_count", C.c_uint32),
         ("reserved0", C.c_uint32),
         ("seed", C.c_uint64),
+        ("progress", C.c_void_p),
+        ("progress_user", C.c_void_p),
     ]
 
 
@@ -439,10 +445,15 @@ class DeviceScene:
         return a
 
     def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0):
+               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None):
         """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats).
-        `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57)."""
+        `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57);
+        `progress(pixels_done, pixels_total)` is called after every finished batch of tiles."""
         a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed)
+        keep = None
+        if progress is not None:
+            keep = PROGRESS_FN(lambda done, total, _user: progress(int(done), int(total)))
+            a.progress = C.cast(keep, C.c_void_p)
         fb = Framebuffer(self.width, self.height)
         ids = RayIds(self.width * self.height * int(sqrt_rays_per_pixel) ** 2, self.n_point_lights) if want_ids else None
         ids_struct = ids.as_struct() if ids is not None else None
@@ -500,22 +511,28 @@ def render(scene: Scene, sqrt_rays_per_pixel: int, antialias_method=AntialiasMet
            device: int = 0, mode: int = RT_MODE_FAST, seed: int = 0) -> Framebuffer:
     """Drop-in for raytracer_lib::render (render.rs:7-12).
 
-    `per_pixel_cb` is accepted for signature parity and called once, after the
-    frame is complete, with no arguments: a GPU backend has no per-pixel moment
-    on the calling thread (the reference calls it once per pixel, render.rs:80-82,
-    only to advance a progress bar).
+    `per_pixel_cb` is called once per pixel of the frame, with no arguments, on the calling
+    thread, as the reference does (render.rs:80-82, where it advances a progress bar) -- but in
+    bursts: a GPU frame finishes in batches of tiles, and the calls for a batch's pixels are made
+    when the batch is done.
     """
+    state = {"done": 0}
+
+    def progress(done, total):
+        for _ in range(done - state["done"]):
+            per_pixel_cb()
+        state["done"] = done
+
     be = Backend(device)
     try:
         ds = be.upload(scene)
         try:
-            fb, _, _ = ds.render(sqrt_rays_per_pixel, antialias_method, mode, seed=seed)
+            fb, _, _ = ds.render(sqrt_rays_per_pixel, antialias_method, mode, seed=seed,
+                                 progress=progress if per_pixel_cb is not None else None)
         finally:
             ds.close()
     finally:
         be.close()
-    if per_pixel_cb is not None:
-        per_pixel_cb()
     return fb
 
 

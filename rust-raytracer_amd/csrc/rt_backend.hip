@@ -693,6 +693,18 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
             RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, stream));
             RT_HIP(hipStreamSynchronize(stream));
+            if (args->progress) {  // pixels of the owned tiles that lie inside the image, finished / in all
+                auto inside = [&](uint32_t from, uint32_t to) {
+                    uint64_t px = 0;
+                    for (uint32_t k = from; k < to; ++k) {
+                        const uint32_t tile = (uint32_t)be->tile_list_host[k];
+                        const uint32_t x0 = (tile % tiles_x) * tw, y0 = (tile / tiles_x) * th;
+                        px += (uint64_t)std::min(tw, W - x0) * std::min(th, H - y0);
+                    }
+                    return px;
+                };
+                args->progress(inside(0, slot0 + slots), inside(0, n_slots), args->progress_user);
+            }
         }
     }
     RT_HIP(hipGetLastError());

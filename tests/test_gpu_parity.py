@@ -249,6 +249,31 @@ def test_headline_workload_matches_oracle_at_full_size(rt, backend, scene_path):
     dev.close()
 
 
+def test_progress_callback_counts_finished_pixels(rt, backend, scene_path):
+    """RtRenderArgs.progress (render.rs:11, 80-82): called after every batch with the pixels finished so
+    far; monotonic, ends at the total, and for a part counts only that part's pixels inside the image."""
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=200, image_height=150, recursion_depth=3)
+    dev = backend.upload(scene)
+    seen = []
+    os.environ["RT_BATCH_SAMPLES"] = str(32 * 32 * 4 * 6)  # six tiles per batch
+    try:
+        fb, _, _ = dev.render(2, progress=lambda done, total: seen.append((done, total)))
+    finally:
+        del os.environ["RT_BATCH_SAMPLES"]
+    assert len(seen) == 6  # 7 x 5 = 35 tiles
+    assert all(t == 200 * 150 for _, t in seen)
+    assert [d for d, _ in seen] == sorted(d for d, _ in seen) and seen[-1][0] == 200 * 150 and seen[0][0] > 0
+    part_seen = []
+    total_px = 0
+    for p in range(3):
+        part_seen.clear()
+        dev.render(2, tile=(32, 32), part=(p, 3), progress=lambda done, total: part_seen.append((done, total)))
+        assert part_seen and part_seen[-1][0] == part_seen[-1][1]
+        total_px += part_seen[-1][1]
+    assert total_px == 200 * 150
+    dev.close()
+
+
 def test_invalid_arguments_are_errors(rt, backend, scene_path):
     scene = rt.parse_scene_file(scene_path("simple_sphere_scene"), image_width=32, image_height=32)
     dev = backend.upload(scene)
@@ -272,7 +297,7 @@ def test_drop_in_render_function(rt, scene_path):
     fb = rt.render(scene, 2, rt.AntialiasMethod.Normal, lambda: calls.append(1))
     ref_fb, _, _ = oracle_lib.render(scene, 2, want_ids=False)
     assert parity.image_metrics(fb.pixels, ref_fb)["max_abs_diff"] <= 1
-    assert fb.width == 64 and fb.height == 48 and calls == [1]
+    assert fb.width == 64 and fb.height == 48 and len(calls) == 64 * 48  # once per pixel, render.rs:80-82
     assert fb.get_pixel(0, 47).tolist() == pytest.approx([0.198] * 3)
 
 
