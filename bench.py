@@ -203,7 +203,9 @@ def main():
     # frames are enqueued back to back without waiting; only the dominant kernel class carries an
     # event pair there (its durations are collected after the loop for the roofline), because
     # every pair drains the pipeline for a few microseconds.
-    warm_stats = [step(True) for _ in range(max(args.warmup, FLIGHTS))]  # every flight at least once
+    # Every flight twice at least: a backend's first frame touches its buffers for the first time, and
+    # the kernel split is read from the last warm-up frame.
+    warm_stats = [step(True) for _ in range(max(args.warmup, 2 * FLIGHTS))]
     fence()
     k_warm = [warm_stats[-1].kernel_ms[k] for k in range(rt.RT_K_COUNT)]
     dom = max(range(len(rt.KERNEL_CLASSES)), key=lambda k: k_warm[k])
