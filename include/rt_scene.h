@@ -47,7 +47,7 @@ enum {
     RT_SHADER_PERFECT_MIRROR = 2,
     RT_SHADER_NORMAL = 3,
     RT_SHADER_NULL = 4,
-    RT_SHADER_GGX_MIRROR = 5 /* parsed, but rendering it is unsupported (OS-seeded RNG) */
+    RT_SHADER_GGX_MIRROR = 5 /* shader/ggx_mirror.rs: roughness (clamped to [0, 1]) and samples */
 };
 typedef struct RtShader {
     int32_t type;

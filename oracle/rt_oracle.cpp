@@ -66,6 +66,57 @@ struct Counters {
     }
 };
 
+// ---------------------------------------------------------------- uniform numbers
+//
+// The reference's stochastic parts call rand::thread_rng().gen::<Real>() (antialias.rs:45-57,
+// ggx_mirror.rs:33-34), an OS-seeded generator: its numbers cannot be reproduced.  The oracle keeps
+// the reference's FORMULAS and takes the uniform numbers from Philox4x32-10 (Salmon et al., SC'11:
+// the round is (c0, c1, c2, c3) -> (hi(M1*c2)^c1^k0, lo(M1*c2), hi(M0*c0)^c3^k1, lo(M0*c0)),
+// M0 = 0xD2511F53, M1 = 0xCD9E8D57, ten rounds, key += (0x9E3779B9, 0xBB67AE85) between rounds),
+// keyed by a seed and counted by the frame-wide sample index, so that another implementation can
+// draw the same.
+struct Philox {
+    uint32_t ctr[4];
+    uint32_t key[2];
+    void round_once() {
+        const uint64_t p0 = 0xD2511F53ull * ctr[0];
+        const uint64_t p1 = 0xCD9E8D57ull * ctr[2];
+        const uint32_t next[4] = {(uint32_t)(p1 >> 32) ^ ctr[1] ^ key[0], (uint32_t)(p1 & 0xffffffffull),
+                                  (uint32_t)(p0 >> 32) ^ ctr[3] ^ key[1], (uint32_t)(p0 & 0xffffffffull)};
+        std::memcpy(ctr, next, sizeof(ctr));
+    }
+    void run() {
+        round_once();
+        for (int r = 1; r < 10; ++r) {
+            key[0] += 0x9E3779B9u;
+            key[1] += 0xBB67AE85u;
+            round_once();
+        }
+    }
+};
+
+// rand 0.8.5 Standard for f64: 53 random bits scaled into [0, 1)
+double unit_from_bits(uint32_t hi, uint32_t lo) {
+    const uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
+    return (double)(bits >> 11) / 9007199254740992.0;
+}
+
+// The numbers one camera sample's shading draws, in the order the reference's recursion asks for
+// them: pair k = Philox(counter (sample low, sample high, k, 1), key seed).  (antialias.rs's
+// offsets use counter (sample low, sample high, 0, 0).)
+struct SampleStream {
+    uint64_t sample = 0, seed = 0;
+    uint32_t pairs_drawn = 0;
+    void next_pair(double &u1, double &u2) {
+        Philox g{{(uint32_t)(sample & 0xffffffffull), (uint32_t)(sample >> 32), pairs_drawn, 1u},
+                 {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)}};
+        g.run();
+        pairs_drawn += 1;
+        u1 = unit_from_bits(g.ctr[0], g.ctr[1]);
+        u2 = unit_from_bits(g.ctr[2], g.ctr[3]);
+    }
+};
+
 // ---------------------------------------------------------------- vectors
 
 template <typename Real>
@@ -207,6 +258,7 @@ struct Hit {
     int ray_class = RC_PRIMARY;
     Counters *counters = nullptr;
     SampleRecord *record = nullptr;
+    struct SampleStream *stream = nullptr;  // uniform numbers of the GGX shader for this camera sample
 
     static Hit make(const Ray<Real> &ray, const Scene<Real> *scene) {  // Hit::new, :17-27
         Hit h;
@@ -645,6 +697,7 @@ Color apply_shader(const Hit<Real> &hit) {
         mirror_hit.ray_class = RC_SECONDARY;
         mirror_hit.counters = hit.counters;
         mirror_hit.record = hit.record;
+        mirror_hit.stream = hit.stream;
         if (hit.counters) hit.counters->rays[RC_SECONDARY]++;
         if (hit.record) hit.record->bounces = mirror_hit.depth;
         if (scene.bvh->closest_hit(mirror_hit)) return apply_shader(mirror_hit);
@@ -653,6 +706,36 @@ Color apply_shader(const Hit<Real> &hit) {
             hit.record->final_tri = -1;
         }
         return scene.background;
+    }
+    case RT_SHADER_GGX_MIRROR: {  // ggx_mirror.rs:54-94
+        if (hit.depth >= scene.recursion_depth) return scene.background;
+        const V3<Real> incoming = hit.ray.direction.normalize();
+        Color accumulated(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < sh.samples; ++k) {
+            // sample_ggx, ggx_mirror.rs:29-51
+            double u1d = 0.0, u2d = 0.0;
+            if (hit.stream) hit.stream->next_pair(u1d, u2d);
+            const Real u1 = (Real)u1d, u2 = (Real)u2d, alpha = (Real)sh.roughness;
+            const Real phi = (Real)2.0 * (Real)3.14159265358979323846 * u1;
+            const Real theta = std::atan(std::sqrt(alpha * alpha * u2 / ((Real)1.0 - u2)));
+            const Real sin_theta = std::sin(theta), cos_theta = std::cos(theta);
+            const Real x = sin_theta * std::cos(phi), y = sin_theta * std::sin(phi), z = cos_theta;
+            // create_coordinate_system, math/coordinate_system.rs:53-62
+            const V3<Real> seed_axis = std::fabs(hit.normal.x) > (Real)0.99 ? V3<Real>(0, 1, 0) : V3<Real>(1, 0, 0);
+            const V3<Real> bitangent = hit.normal.cross(seed_axis).normalize();
+            const V3<Real> tangent = bitangent.cross(hit.normal).normalize();
+            const V3<Real> micro_normal = tangent * x + bitangent * y + hit.normal * z;
+            const V3<Real> outgoing = incoming - micro_normal * ((Real)2.0 * incoming.dot(micro_normal));
+            Hit<Real> mirror_hit = Hit<Real>::make(Ray<Real>{hit.hit_point(), outgoing.normalize()}, &scene);
+            mirror_hit.depth = (uint16_t)(hit.depth + 1);
+            mirror_hit.t_min = (Real)1e-6;
+            mirror_hit.ray_class = RC_SECONDARY;
+            mirror_hit.counters = hit.counters;
+            mirror_hit.stream = hit.stream;
+            if (hit.counters) hit.counters->rays[RC_SECONDARY]++;
+            accumulated += scene.bvh->closest_hit(mirror_hit) ? apply_shader(mirror_hit) : scene.background;
+        }
+        return accumulated / (float)sh.samples;
     }
     case RT_SHADER_NORMAL:  // normal.rs:10-16
         if (hit.record) {
@@ -672,38 +755,6 @@ Color apply_shader(const Hit<Real> &hit) {
 }
 
 // ---------------------------------------------------------------- antialias.rs
-
-// The reference's jittered / random methods call rand::thread_rng().gen::<Real>() (antialias.rs:45-57),
-// an OS-seeded generator: its numbers cannot be reproduced.  The oracle keeps the reference's
-// FORMULAS and takes the uniform numbers from Philox4x32-10 (Salmon et al., SC'11: the round is
-// (c0, c1, c2, c3) -> (hi(M1*c2)^c1^k0, lo(M1*c2), hi(M0*c0)^c3^k1, lo(M0*c0)), M0 = 0xD2511F53,
-// M1 = 0xCD9E8D57, ten rounds, key += (0x9E3779B9, 0xBB67AE85) between rounds), keyed by a seed
-// and counted by the frame-wide sample index, so that another implementation can draw the same.
-struct Philox {
-    uint32_t ctr[4];
-    uint32_t key[2];
-    void round_once() {
-        const uint64_t p0 = 0xD2511F53ull * ctr[0];
-        const uint64_t p1 = 0xCD9E8D57ull * ctr[2];
-        const uint32_t next[4] = {(uint32_t)(p1 >> 32) ^ ctr[1] ^ key[0], (uint32_t)(p1 & 0xffffffffull),
-                                  (uint32_t)(p0 >> 32) ^ ctr[3] ^ key[1], (uint32_t)(p0 & 0xffffffffull)};
-        std::memcpy(ctr, next, sizeof(ctr));
-    }
-    void run() {
-        round_once();
-        for (int r = 1; r < 10; ++r) {
-            key[0] += 0x9E3779B9u;
-            key[1] += 0xBB67AE85u;
-            round_once();
-        }
-    }
-};
-
-// rand 0.8.5 Standard for f64: 53 random bits scaled into [0, 1)
-double unit_from_bits(uint32_t hi, uint32_t lo) {
-    const uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
-    return (double)(bits >> 11) / 9007199254740992.0;
-}
 
 // antialias.rs:26-57.  method: 0 normal, 1 jittered, 2 random.
 template <typename Real>
@@ -733,8 +784,6 @@ template <typename Real>
 int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int threads, float *fb,
                 const OracleOutputs *out, OracleCounters *counters_out) {
     if (aa_method < 0 || aa_method > 2) return -1;
-    for (uint32_t i = 0; i < rs.n_shaders; ++i)
-        if (rs.shaders[i].type == RT_SHADER_GGX_MIRROR) return -3;
     Scene<Real> scene(rs);
     const uint32_t W = scene.image_width, H = scene.image_height;
     const int npl = scene.n_point_lights;
@@ -760,6 +809,10 @@ int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int
                         antialias<Real>(aa_method, seed, (uint64_t)s, n, p, q, di, dj);
                         Hit<Real> hit = Hit<Real>::make(scene.camera.generate_ray(i, j, di, dj), &scene);
                         hit.counters = &local;
+                        SampleStream stream;
+                        stream.sample = (uint64_t)s;
+                        stream.seed = seed;
+                        hit.stream = &stream;
                         SampleRecord rec;
                         if (out) {
                             if (out->shadow_shape) {

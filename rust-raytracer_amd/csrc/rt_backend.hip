@@ -26,6 +26,7 @@
 #include "rt_error.h"
 #include "rt_pipeline.h"
 #include "rt_packet.h"
+#include "rt_tree.h"
 // Register budgets (waves per SIMD the compiler must make room for; 512 VGPRs / waves).  These
 // kernels wait on memory most of the time, so one more resident wave is worth more than the
 // handful of values that get spilled for it -- as long as the spills stay out of the loops:
@@ -199,6 +200,29 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
         if (!live[k]) continue;
         if (KIND == 1) shadow_store(Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
         else closest_store(Q, base + (uint32_t)k * RT_PACKET_BLOCK, st[k].t, st[k].shape, st[k].tri);
+    }
+}
+
+// ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
+// The traversal stack lives in LDS like the per-lane kernels'; the tree's own stack of waiting
+// GGX hits is per-thread scratch memory.
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples) {
+    extern __shared__ int32_t lds[];
+    LdsStack stk{lds + threadIdx.x, S.stack_depth};
+    const uint32_t ls = blockIdx.x * RT_BLOCK + threadIdx.x;
+    TreeCounts counts = {0ull, 0ull, 0ull};
+    if (ls < n_samples) tree_body<LdsStack, FAST>(S, Q, B, ids, ls, stk, counts);
+    // one atomic per wave and counter
+    for (int d = 32; d > 0; d >>= 1) {
+        counts.secondary += __shfl_down(counts.secondary, d, 64);
+        counts.shadow += __shfl_down(counts.shadow, d, 64);
+        counts.shaded += __shfl_down(counts.shaded, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&Q.counters[RT_CNT_TREE_SECONDARY]), counts.secondary);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&Q.counters[RT_CNT_TREE_SHADOW]), counts.shadow);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&Q.counters[RT_CNT_TREE_SHADED]), counts.shaded);
     }
 }
 
@@ -419,6 +443,7 @@ struct RtDeviceScene {
     uint32_t n_point_lights = 0;
     bool has_mirror = false;
     bool has_lit = false;
+    bool has_ggx = false;  // a shape uses GGXMirror: frames go through the ray-tree kernel
 };
 
 namespace {
@@ -638,6 +663,14 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
+        if (ds->has_ggx) {  // the ray-tree path replaces stages 1-5
+            if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            if (ref_order)
+                hipLaunchKernelGGL((k_render_tree<false>), dim3(full_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, n_samples);
+            else
+                hipLaunchKernelGGL((k_render_tree<true>), dim3(full_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, n_samples);
+            tm.end();
+        } else {
         // chunk of the XCD remap, in 256-sample blocks: 128 (a few tiles) for a whole frame, smaller
         // for a small launch so that every XCD still gets >= 32 chunks -- chunks differ in cost, and
         // with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
@@ -681,6 +714,7 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
             tm.end();
+        }
         }
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(B.n_pixels)), dim3(RT_BLOCK), 0, stream, Q, B, fb_dev);
@@ -731,9 +765,16 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         }
         for (size_t at = 0; at < host_counters.size(); at += RT_CNT_SIZE) {
             const uint32_t *c = host_counters.data() + at;
-            for (int b = 1; b <= max_bounce && b < 32; ++b) stats->secondary_rays += c[RT_CNT_RAYS0 + b];
-            stats->shaded_hits += c[RT_CNT_LIT];
-            if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_LIT] * ds->n_point_lights;
+            if (ds->has_ggx) {
+                auto wide = [&](int at) { return (uint64_t)c[at] | ((uint64_t)c[at + 1] << 32); };
+                stats->secondary_rays += wide(RT_CNT_TREE_SECONDARY);
+                stats->shadow_rays += wide(RT_CNT_TREE_SHADOW);
+                stats->shaded_hits += wide(RT_CNT_TREE_SHADED);
+            } else {
+                for (int b = 1; b <= max_bounce && b < 32; ++b) stats->secondary_rays += c[RT_CNT_RAYS0 + b];
+                stats->shaded_hits += c[RT_CNT_LIT];
+                if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_LIT] * ds->n_point_lights;
+            }
             overflow = overflow || c[RT_CNT_OVERFLOW] != 0;
         }
         if (overflow) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
@@ -785,15 +826,13 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
 extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScene **out) {
     if (!be || !scene || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
     *out = nullptr;
-    for (uint32_t i = 0; i < scene->n_shaders; ++i)
-        if (scene->shaders[i].type == RT_SHADER_GGX_MIRROR) {
-            // only an error if a shape actually uses it
-            for (uint32_t s = 0; s < scene->n_shapes; ++s)
-                if (scene->shapes[s].shader == (int32_t)i)
-                    return rt::set_error(RT_ERR_UNSUPPORTED,
-                                         "GGXMirror samples an OS-seeded RNG in the reference and has no "
-                                         "reproducible definition");
-        }
+    bool uses_ggx = false;
+    for (uint32_t s = 0; s < scene->n_shapes; ++s) {
+        const int32_t sh = scene->shapes[s].shader;
+        uses_ggx = uses_ggx || (sh >= 0 && (uint32_t)sh < scene->n_shaders && scene->shaders[sh].type == RT_SHADER_GGX_MIRROR);
+    }
+    if (uses_ggx && scene->recursion_depth > RT_TREE_MAX_DEPTH)
+        return rt::set_error(RT_ERR_UNSUPPORTED, "GGXMirror with a recursion depth above " + std::to_string(RT_TREE_MAX_DEPTH));
     rt::FlatScene flat;
     const std::string err = rt::flatten_scene(*scene, flat);
     if (!err.empty()) return rt::set_error(RT_ERR_INVALID, err);
@@ -850,6 +889,7 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
         ds->has_mirror = ds->has_mirror || t == RT_SHADER_PERFECT_MIRROR;
         ds->has_lit = ds->has_lit || t == RT_SHADER_LAMBERTIAN || t == RT_SHADER_BLINN_PHONG;
     }
+    ds->has_ggx = uses_ggx;
     *out = ds;
     return RT_OK;
 }

@@ -65,6 +65,10 @@ enum {
     RT_CNT_RAYS0 = 0,      // [1 .. 31]: rays in the queue of bounce b (b >= 1)
     RT_CNT_LIT = 32,       // lit hits of the batch
     RT_CNT_OVERFLOW = 33,  // traversal-stack overflows (must stay 0)
+    // ray-tree path (rt_tree.h): 64-bit counts, two dwords each
+    RT_CNT_TREE_SECONDARY = 34,
+    RT_CNT_TREE_SHADOW = 36,
+    RT_CNT_TREE_SHADED = 38,
     RT_CNT_SIZE = 40
 };
 

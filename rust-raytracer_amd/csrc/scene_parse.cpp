@@ -573,7 +573,8 @@ SceneOwner *build_scene(const char *json_text, const std::string &data_path, con
             rs.type = RT_SHADER_PERFECT_MIRROR;
         } else if (type == "GGXMirror") {
             rs.type = RT_SHADER_GGX_MIRROR;
-            rs.roughness = require_number(sd, {"roughness"}, name.c_str());
+            // GGXMirrorShader::new clamps (ggx_mirror.rs:14-17); RtShader holds what the constructor holds
+            rs.roughness = std::fmin(std::fmax(require_number(sd, {"roughness"}, name.c_str()), 0.0), 1.0);
             rs.samples = (uint32_t)require_number(sd, {"samples"}, name.c_str());
         } else if (type == "Diffuse" || type == "BlinnPhongMirror" || type == "BlinnPhongMirrored" ||
                    type == "Glaze" || type == "Dielectric") {

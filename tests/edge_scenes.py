@@ -64,3 +64,23 @@ def scenes(tmp_dir):
 
 NAMES = ["no_lights", "ambient_only", "one_shape", "one_pixel", "wide_aspect", "odd_size_many_samples", "camera_inside_box",
          "mirror_pair", "degenerate_mesh", "scaled_instances"]
+
+
+def ggx_scene(roughness=0.25, samples=3, mirror_type=None):
+    """Two rough mirrors (GGXMirror, ggx_mirror.rs) facing each other and a perfect mirror, over a lit floor
+    and a lit ball: GGX hits under GGX hits, GGX under a mirror, lit hits at every depth.  With
+    `mirror_type` the rough shader is replaced by that type (for comparisons)."""
+    rough = ({"_name": "rough", "_type": "GGXMirror", "roughness": roughness, "samples": samples} if mirror_type is None
+             else {"_name": "rough", "_type": mirror_type})
+    shaders = SHADERS + [rough]
+    shapes = [
+        {"_name": "g1", "_type": "sphere", "shader": "rough", "center": "-1.3 0 0", "radius": 1.0},
+        {"_name": "g2", "_type": "box", "shader": "rough", "minPt": "0.9 -1.0 -1.6", "maxPt": "1.1 1.4 0.9"},
+        {"_name": "m", "_type": "sphere", "shader": "mir", "center": "0.1 -0.45 1.4", "radius": 0.5},
+        {"_name": "ball", "_type": "sphere", "shader": "bp", "center": "0 1.3 -0.8", "radius": 0.6},
+        {"_name": "tri", "_type": "triangle", "shader": "lam", "v0": "-3 -1 -3", "v1": "3 -1 -3", "v2": "0 3.5 -3.4"},
+        BALLS[2],
+    ]
+    return json.dumps({"scene": {"camera": CAM, "shader": shaders, "shape": shapes,
+                                 "light": [POINT, {"_type": "point", "position": "-4 2.5 3", "intensity": "0.5 0.5 0.6"}, AMBIENT],
+                                 "sceneParameters": {"bgColor": "0.2 0.25 0.35"}}})

@@ -30,6 +30,7 @@ static thread_local std::vector<int32_t> *g_visit[2];
 #include "../../include/rt_hip.h"
 #include "../../rust-raytracer_amd/csrc/bvh_build.h"
 #include "../../rust-raytracer_amd/csrc/rt_pipeline.h"
+#include "../../rust-raytracer_amd/csrc/rt_tree.h"
 
 // Optional per-ray work recording (nodes fetched, triangles tested), for divergence studies:
 // [0] camera rays per sample, [1] shadow rays per (light, sample); null = off.
@@ -60,7 +61,7 @@ struct HostScene {
     rt::FlatScene flat;
     std::vector<int32_t> point_lights;
     RtSceneView view{}, view_fast{};  // reference-order / fast mode (different scene-level trees)
-    bool has_mirror = false, has_lit = false;
+    bool has_mirror = false, has_lit = false, has_ggx = false;
 };
 
 std::string make_view(const RtScene &scene, HostScene &hs) {
@@ -95,6 +96,7 @@ std::string make_view(const RtScene &scene, HostScene &hs) {
         const int32_t t = scene.shaders[scene.shapes[s].shader].type;
         hs.has_mirror = hs.has_mirror || t == RT_SHADER_PERFECT_MIRROR;
         hs.has_lit = hs.has_lit || t == RT_SHADER_LAMBERTIAN || t == RT_SHADER_BLINN_PHONG;
+        hs.has_ggx = hs.has_ggx || t == RT_SHADER_GGX_MIRROR;
     }
     return "";
 }
@@ -186,6 +188,33 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     };
 
     const long n_samples = (long)B.n_pixels * spp;
+    if (hs.has_ggx) {  // the ray-tree path (rt_tree.h), as the backend takes it
+        unsigned long long secondary = 0, shadow = 0, shaded = 0, primary = 0;
+#pragma omp parallel reduction(+ : secondary, shadow, shaded, primary)
+        {
+            VecStack stk;
+            stk.v.assign((size_t)std::max(S.stack_depth, 1), 0);
+            TreeCounts counts = {0ull, 0ull, 0ull};
+#pragma omp for schedule(dynamic, 256)
+            for (long ls = 0; ls < n_samples; ++ls) {
+                uint32_t i, j;
+                primary += batch_pixel(B, (uint32_t)(ls / spp), i, j) ? 1 : 0;
+                tree_body<VecStack, !EXACT>(S, Q, B, io, (uint32_t)ls, stk, counts);
+            }
+            secondary += counts.secondary; shadow += counts.shadow; shaded += counts.shaded;
+        }
+#pragma omp parallel for schedule(static, 4096)
+        for (long lp = 0; lp < (long)B.n_pixels; ++lp) resolve_body(Q, B, (uint32_t)lp, fb);
+        if (stats) {
+            std::memset(stats, 0, sizeof(*stats));
+            stats->primary_rays = primary;
+            stats->secondary_rays = secondary;
+            stats->shadow_rays = shadow;
+            stats->shaded_hits = shaded;
+            stats->kernel_launches[0] = Q.counters[RT_CNT_OVERFLOW];
+        }
+        return;
+    }
     const int max_bounce = hs.has_mirror ? S.recursion_depth : 0;
     for (int bounce = 0; bounce <= max_bounce; ++bounce) {
         const long count = bounce == 0 ? n_samples : (long)Q.counters[RT_CNT_RAYS0 + bounce];

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import edge_scenes
 import oracle_lib
 import parity
 
@@ -272,6 +273,50 @@ def test_progress_callback_counts_finished_pixels(rt, backend, scene_path):
         total_px += part_seen[-1][1]
     assert total_px == 200 * 150
     dev.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ggx_ray_trees_match_oracle(rt, backend, mode):
+    """GGXMirror (shader/ggx_mirror.rs): every hit spawns `samples` reflected rays, recursively.  Scenes
+    that use it go through the ray-tree kernel; both sides draw the same numbers in the order of the
+    reference's recursion, so the frames compare like deterministic ones."""
+    scene = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=160, image_height=120, recursion_depth=3)
+    dev = backend.upload(scene)
+    ref_fb, ref_ids, counters = oracle_lib.render(scene, 2, seed=2024)
+    fb, ids, stats = dev.render(2, mode=mode, want_ids=True, seed=2024)
+    m = parity.image_metrics(fb.pixels, ref_fb)
+    assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, m
+    assert (ids.primary_shape == ref_ids.primary_shape).mean() >= 0.9999
+    got = [stats.primary_rays, stats.secondary_rays, stats.shadow_rays]
+    assert counters["rays"][1] > 3 * 160 * 120  # the trees do fan out
+    for g, r in zip(got, counters["rays"]):
+        assert abs(g - r) <= max(4, r // 2000), (got, counters["rays"])
+    again, _, _ = dev.render(2, mode=mode, seed=2024)
+    other, _, _ = dev.render(2, mode=mode, seed=2025)
+    assert np.array_equal(again.pixels, fb.pixels) and not np.array_equal(other.pixels, fb.pixels)
+    whole = np.zeros_like(fb.pixels)
+    for p in range(3):
+        part, _, _ = dev.render(2, mode=mode, seed=2024, tile=(16, 16), part=(p, 3))
+        whole += part.pixels
+    assert np.array_equal(whole, fb.pixels)
+    dev.close()
+
+
+def test_ggx_limits(rt, backend):
+    """Roughness 0 with one sample is a perfect mirror; trees deeper than the kernel's frame stack
+    are refused, not truncated."""
+    smooth = rt.parse_scene(edge_scenes.ggx_scene(roughness=0.0, samples=1), "", image_width=120, image_height=90, recursion_depth=4)
+    mirror = rt.parse_scene(edge_scenes.ggx_scene(mirror_type="Mirror"), "", image_width=120, image_height=90, recursion_depth=4)
+    da, db = backend.upload(smooth), backend.upload(mirror)
+    a, _, _ = da.render(2)
+    b, _, _ = db.render(2)
+    assert parity.image_metrics(a.pixels, b.pixels)["lsb1_fraction"] >= 0.995
+    da.close()
+    db.close()
+    deep = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=16, image_height=16, recursion_depth=17)
+    with pytest.raises(rt.RtError) as e:
+        backend.upload(deep)
+    assert e.value.code == rt.RT_ERR_UNSUPPORTED
 
 
 def test_invalid_arguments_are_errors(rt, backend, scene_path):

@@ -144,3 +144,53 @@ def test_corner_case_scenes(rt, tmp_path, name):
         assert np.array_equal(ids.shadow_shape >= 0, ids_o.shadow_shape >= 0)
         assert parity.image_metrics(fb, fb_o)["max_abs_diff"] <= 1
         assert stats.total_rays() == sum(cnt["rays"])
+
+
+# ---- GGXMirror (shader/ggx_mirror.rs): the ray-tree path
+
+def _ggx_check(rt, fb, ids, stats, fb_o, ids_o, cnt):
+    m = parity.image_metrics(fb, fb_o)
+    assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, m
+    assert (ids.primary_shape == ids_o.primary_shape).mean() >= 0.9999
+    got = [int(stats.primary_rays), int(stats.secondary_rays), int(stats.shadow_rays)]
+    for g, r in zip(got, cnt["rays"]):
+        assert abs(g - r) <= max(4, r // 2000), (got, cnt["rays"])
+
+
+@pytest.mark.parametrize("mode", ["fast", "reference_order"])
+def test_ggx_ray_trees_match_oracle(rt, mode):
+    """Every GGX hit spawns `samples` reflected rays, recursively; both sides draw the same numbers in
+    the order of the reference's recursion, so frames compare like deterministic ones."""
+    sc = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=96, image_height=72, recursion_depth=3)
+    fb_o, ids_o, cnt = O.render(sc, 2, seed=77)
+    assert cnt["rays"][1] > 3 * 96 * 72  # the trees do fan out
+    m = rt.RT_MODE_FAST if mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
+    fb, ids, stats = HS.render(sc, 2, mode=m, seed=77)
+    _ggx_check(rt, fb, ids, stats, fb_o, ids_o, cnt)
+    other, _, _ = HS.render(sc, 2, mode=m, seed=78, want_ids=False)
+    assert not np.array_equal(other, fb)
+    whole = np.zeros_like(fb)
+    for p in range(2):
+        part, _, _ = HS.render(sc, 2, mode=m, seed=77, want_ids=False, tile=(16, 16), part=(p, 2))
+        whole += part
+    assert np.array_equal(whole, fb)
+
+
+def test_ggx_limits(rt):
+    """Roughness 0 with one sample is a perfect mirror (the microfacet normal is the surface normal);
+    recursion depth 0 shows the background on every rough surface; jittered offsets and GGX draws
+    come from separate streams."""
+    smooth = rt.parse_scene(edge_scenes.ggx_scene(roughness=0.0, samples=1), "", image_width=80, image_height=60, recursion_depth=4)
+    mirror = rt.parse_scene(edge_scenes.ggx_scene(mirror_type="Mirror"), "", image_width=80, image_height=60, recursion_depth=4)
+    a, _, _ = HS.render(smooth, 2, want_ids=False)
+    b, _, _ = HS.render(mirror, 2, want_ids=False)
+    assert parity.image_metrics(a, b)["lsb1_fraction"] >= 0.995
+    flat = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=80, image_height=60, recursion_depth=0)
+    fb, ids, stats = HS.render(flat, 1)
+    fb_o, ids_o, cnt = O.render(flat, 1)
+    assert stats.secondary_rays == 0 == cnt["rays"][1]
+    assert parity.image_metrics(fb, fb_o)["max_abs_diff"] <= 1
+    sc = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=64, image_height=48, recursion_depth=2)
+    fb_o, ids_o, cnt = O.render(sc, 2, aa=1, seed=5)
+    fb, ids, stats = HS.render(sc, 2, aa=1, seed=5)
+    _ggx_check(rt, fb, ids, stats, fb_o, ids_o, cnt)
