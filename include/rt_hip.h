@@ -100,7 +100,10 @@ void rt_scene_free(RtDeviceScene *dev_scene);
  * (i + j * width) * n * n + p * n + q.  Of the four output words x0..x3,
  * r1 = ((x0 << 32 | x1) >> 11) * 2^-53 and r2 likewise from x2, x3 (53 random bits, like
  * rand's f64).  A frame therefore depends only on (scene, n, method, seed): not on the
- * tiling, the partition over GPUs or the traversal mode. */
+ * tiling, the partition over GPUs or the traversal mode.
+ * GGXMirror (ggx_mirror.rs:33-34, two uniform numbers per reflected ray) draws from the same
+ * generator: the k-th pair of a sample, k counted in the order of the reference's recursion, has
+ * counter (sample index low word, high word, k, 1). */
 enum { RT_AA_NORMAL = 0, RT_AA_JITTERED = 1, RT_AA_RANDOM = 2 };
 
 /* Traversal policy.  Both produce the same closest hits except at exact ties.
@@ -147,7 +150,9 @@ typedef struct RtRenderArgs {
  *   s = (i + j * width) * n*n + p * n + q     (render.rs:64-65 loop order).
  * Any pointer may be NULL.  Shape ids index RtScene.shapes; tri ids index the
  * mesh's triangles in file order (-1 when the hit is not inside a mesh).
- * -1 in a shape id means "no hit". */
+ * -1 in a shape id means "no hit".
+ * Scenes that use GGXMirror (shader/ggx_mirror.rs) trace a TREE of rays per sample: only
+ * primary_shape / primary_tri are defined for them (final_* = -1, bounces = 0, shadow_* = -2). */
 typedef struct RtRayIds {
     int32_t *primary_shape; /* first hit of the camera ray */
     int32_t *primary_tri;

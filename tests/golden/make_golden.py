@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Writes tests/golden/render_<scene>.npz: the CPU oracle's framebuffer, per-sample ids and ray
 counts for every test scene at 64x48, 4 rays per pixel, depth 6, and
-render_<scene>_<method>.npz for the two stochastic antialiasing methods (seed 2024) on two scenes.
+render_<scene>_<method>.npz for the two stochastic antialiasing methods (seed 2024) on two scenes,
+and render_ggx_scene.npz for the GGX ray trees.
 
     python3 tests/golden/make_golden.py
 
@@ -49,6 +50,13 @@ def main():
                             shaded_hits=np.int64(cnt["shaded_hits"]), method=np.int64(method),
                             seed=np.int64(STOCHASTIC_SEED), **arrays)
         print(name, label, cnt["rays"])
+    # GGXMirror ray trees (tests/edge_scenes.py::ggx_scene), seed 2024, depth 3
+    import edge_scenes
+    sc = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=WIDTH, image_height=HEIGHT, recursion_depth=3)
+    fb, ids, cnt = O.render(sc, SQRT_RPP, threads=1, seed=STOCHASTIC_SEED)
+    np.savez_compressed(os.path.join(HERE, "render_ggx_scene.npz"), fb=fb, rays=np.array(cnt["rays"], np.int64),
+                        seed=np.int64(STOCHASTIC_SEED), primary_shape=ids.primary_shape, primary_tri=ids.primary_tri)
+    print("ggx_scene", cnt["rays"])
 
 
 if __name__ == "__main__":

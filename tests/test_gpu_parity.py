@@ -302,6 +302,19 @@ def test_ggx_ray_trees_match_oracle(rt, backend, mode):
     dev.close()
 
 
+def test_ggx_matches_committed_fixture(rt, backend):
+    g = np.load(os.path.join(GOLDEN, "render_ggx_scene.npz"))
+    scene = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=64, image_height=48, recursion_depth=3)
+    dev = backend.upload(scene)
+    fb, ids, stats = dev.render(2, mode=rt.RT_MODE_REFERENCE_ORDER, want_ids=True, seed=int(g["seed"]))
+    m = parity.image_metrics(fb.pixels, g["fb"])
+    assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, m
+    assert (ids.primary_shape == g["primary_shape"]).mean() >= 0.9999 and (ids.primary_tri == g["primary_tri"]).mean() >= 0.9999
+    for got, want in zip([stats.primary_rays, stats.secondary_rays, stats.shadow_rays], g["rays"].tolist()):
+        assert abs(got - want) <= max(4, want // 2000)
+    dev.close()
+
+
 def test_ggx_limits(rt, backend):
     """Roughness 0 with one sample is a perfect mirror; trees deeper than the kernel's frame stack
     are refused, not truncated."""
