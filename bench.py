@@ -118,7 +118,7 @@ def main():
     # overlaps the next frame's work instead of idling the GPU.  Measured on one MI355X for this
     # frame cut into 8 parts: 0.54 ms per part-frame with one frame in flight, 0.28 ms with four
     # (the whole frame: 1.82 -> 1.76 ms).
-    FLIGHTS = 4
+    FLIGHTS = int(os.environ.get("RT_BENCH_FLIGHTS", "4"))  # frames in flight per GPU (3 to 8 measure within 2 % of each other, 2 is 9 % slower)
     backends = [rt.Backend(local_rank) for _ in range(FLIGHTS)]
     t_up = time.perf_counter()
     devs = [be.upload(scene) for be in backends]
