@@ -10,7 +10,9 @@
 //     stack level fall on 64 consecutive dwords; a queue's length lives in device memory
 //     (written by the previous stage's wave-wide ballot allocations), so no stage needs a host
 //     round trip to learn its size;
-//   * shade / accumulate / resolve: one thread per sample or pixel.
+//   * shade / accumulate / resolve: one thread per sample or pixel;
+//   * scenes with a GGX shader: one thread per sample walks the sample's whole ray tree
+//     (rt_tree.h) in place of the trace / shade / accumulate stages.
 
 #include <hip/hip_runtime.h>
 

@@ -540,14 +540,16 @@ RT_HD bool traverse(const RtSceneView &S, RayF ray, float tmin, HitF &hit, int32
 
 // ---------------------------------------------------------------- fast-mode traversal
 //
-// Same tree, same primitives, same closest hit as traverse<> above (ties aside), but the
-// arithmetic is arranged for the GPU rather than to mirror the reference line by line:
-//   * node test: (p - o) * (1/d) with min/max per axis instead of a sign-selected swap.
-//     1/d is clamped to +-FLT_MAX so that 0 * (1/0) is 0, not NaN: a ray lying in a box
-//     face's plane then treats that axis as unconstrained on the entry side like the
+// Same primitives, same closest hit as traverse<> above (ties aside; the mesh trees are the same,
+// the scene-level tree is the fast mode's own), but the arithmetic is arranged for the GPU
+// rather than to mirror the reference line by line:
+//   * node test: p * (1/d) - o * (1/d) as packed multiply-adds, with min/max per axis instead of
+//     a sign-selected swap.  1/d is clamped to +-2^62 so that 0 * (1/0) is 0, not NaN: a ray lying
+//     in a box face's plane then treats that axis as unconstrained on the entry side like the
 //     reference does.  The test only culls; primitives decide hits.
-//   * triangle test: the four determinants of triangle.rs:76-105 share their two cross
-//     products and one reciprocal of det A replaces the three divisions.
+//   * triangle test: an affine map per triangle (RtTriXf) gives the plane distance and both
+//     barycentrics as dot products, with one reciprocal instead of triangle.rs:76-105's four
+//     determinants and three divisions.
 // It is written as begin / step: one step walks inner nodes to the next leaf and processes it.
 
 // Pairs of floats as the packed fp32 instructions (v_pk_fma_f32: two multiply-adds per lane per

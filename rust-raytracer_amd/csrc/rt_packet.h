@@ -7,8 +7,8 @@
 // only owns its ray, its closest hit so far and its vote on where to go next:
 //
 //   * a child is entered if ANY lane's ray enters its box (wave ballot); the child on the
-//     side most of the wave's rays come from (split axis of the node against the majority sign
-//     of the ray directions) is visited first, the other one is pushed;
+//     side most of the wave's rays come from (the node's right_first_mask against the direction
+//     octant of the wave) is visited first, the other one is pushed;
 //   * every lane tests every primitive of a visited leaf; a lane whose ray does not reach the
 //     leaf's box simply finds no hit there;
 //   * an any-hit lane that has found its blocker sets its search bound to -inf, so all its
