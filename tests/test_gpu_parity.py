@@ -250,6 +250,20 @@ def test_headline_workload_matches_oracle_at_full_size(rt, backend, scene_path):
     dev.close()
 
 
+@pytest.mark.parametrize("name", ["spheres_1K", "cornell_room", "spheres_and_triangles"])
+def test_other_workloads_match_oracle_at_full_size(rt, backend, scene_path, name):
+    """The other 1000x1000 / 9 rays per pixel / depth 6 configurations, every sample compared (7-deep
+    mirror chains in cornell_room; a 511-node scene-level tree in spheres_1K)."""
+    scene = rt.parse_scene_file(scene_path(name), image_width=1000, image_height=1000, recursion_depth=6)
+    dev = backend.upload(scene)
+    fb, ids, stats = dev.render(3, want_ids=True)
+    ref_fb, ref_ids, counters = oracle_lib.render(scene, 3, want_ids=True)
+    im, idm = parity.assert_parity(fb.pixels, ids, ref_fb, ref_ids, occlusion_only=True, label=name + " 1000^2")
+    print(name, "1000^2 parity:", im, idm)
+    assert abs(stats.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
+    dev.close()
+
+
 def test_progress_callback_counts_finished_pixels(rt, backend, scene_path):
     """RtRenderArgs.progress (render.rs:11, 80-82): called after every batch with the pixels finished so
     far; monotonic, ends at the total, and for a part counts only that part's pixels inside the image."""
