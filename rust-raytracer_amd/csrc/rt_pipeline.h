@@ -30,6 +30,17 @@
 #include "rt_core.h"
 
 // Device buffers of one batch of samples (structure of arrays).
+// Accesses to the per-batch work buffers (written once by one stage, read once by a later one):
+// on the device they carry the non-temporal hint, so that these hundreds of megabytes per frame
+// pass by the L2 lines that hold the trees and triangles, which every wave keeps coming back to.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_STREAM_ST(lvalue, value) __builtin_nontemporal_store((value), &(lvalue))
+#define RT_STREAM_LD(lvalue) __builtin_nontemporal_load(&(lvalue))
+#else
+#define RT_STREAM_ST(lvalue, value) ((lvalue) = (value))
+#define RT_STREAM_LD(lvalue) (lvalue)
+#endif
+
 struct RtBuffers {
     // mirror-ray queues, ping-pong by bounce parity: bounce b reads q[b & 1], writes q[(b + 1) & 1]
     double *q_o[2][3];
@@ -174,9 +185,9 @@ RT_HD bool closest_setup(const RtSceneView &S, const RtBuffers &Q, const RtBatch
 }
 
 RT_HD void closest_store(const RtBuffers &Q, uint32_t idx, float t, int32_t shape, int32_t tri) {
-    Q.h_t[idx] = t;
-    Q.h_shape[idx] = shape;
-    Q.h_tri[idx] = tri;
+    RT_STREAM_ST(Q.h_t[idx], t);
+    RT_STREAM_ST(Q.h_shape[idx], shape);
+    RT_STREAM_ST(Q.h_tri[idx], tri);
 }
 
 // Reference-shaped traversal of one ray (both modes can use it; the fast mode's kernels
@@ -231,7 +242,7 @@ struct MirrorTmp {
 
 RT_HD void write_color(const RtBuffers &Q, int32_t sample, float r, float g, float b) {
     float *c = Q.color + (size_t)sample * 3;
-    c[0] = r; c[1] = g; c[2] = b;
+    RT_STREAM_ST(c[0], r); RT_STREAM_ST(c[1], g); RT_STREAM_ST(c[2], b);
 }
 
 // Decides what happens to one traced ray (shader/*.rs apply()).  Colours that need
@@ -251,7 +262,7 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         sample = Q.q_sample[which][idx];
         queue_read_ray(Q, which, idx, o, d);
     }
-    const int32_t shape = Q.h_shape[idx], gtri = Q.h_tri[idx];
+    const int32_t shape = RT_STREAM_LD(Q.h_shape[idx]), gtri = RT_STREAM_LD(Q.h_tri[idx]);
     const bool want_ids = ids.primary_shape || ids.primary_tri || ids.final_shape || ids.final_tri || ids.bounces;
     const size_t gs = want_ids ? global_sample(B, (uint32_t)sample) : 0;
     const int32_t ftri = tri_file_index(S, gtri);
@@ -267,7 +278,7 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         return RT_ACT_NONE;
     }
     const double tmin = bounce == 0 ? 1.0 : RT_VERY_SMALL_NUMBER;
-    double t = (double)Q.h_t[idx];
+    double t = (double)RT_STREAM_LD(Q.h_t[idx]);
     D3 n;
     exact_prim_hit(S, shape, gtri, o, d, tmin, (double)__builtin_inff(), true, t, t, &n);
     const D3 p = o + d * t;  // Hit::hit_point, hit_struct.rs:41-43
@@ -275,9 +286,9 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
     switch (sh.type) {
     case RT_SHADER_LAMBERTIAN:
     case RT_SHADER_BLINN_PHONG: {
-        Q.l_p[0][sample] = p.x; Q.l_p[1][sample] = p.y; Q.l_p[2][sample] = p.z;
-        Q.l_n[0][sample] = n.x; Q.l_n[1][sample] = n.y; Q.l_n[2][sample] = n.z;
-        Q.l_d[0][sample] = d.x; Q.l_d[1][sample] = d.y; Q.l_d[2][sample] = d.z;
+        RT_STREAM_ST(Q.l_p[0][sample], p.x); RT_STREAM_ST(Q.l_p[1][sample], p.y); RT_STREAM_ST(Q.l_p[2][sample], p.z);
+        RT_STREAM_ST(Q.l_n[0][sample], n.x); RT_STREAM_ST(Q.l_n[1][sample], n.y); RT_STREAM_ST(Q.l_n[2][sample], n.z);
+        RT_STREAM_ST(Q.l_d[0][sample], d.x); RT_STREAM_ST(Q.l_d[1][sample], d.y); RT_STREAM_ST(Q.l_d[2][sample], d.z);
         Q.l_shape[sample] = shape;
         Q.l_tri[sample] = gtri;
         if (!S.disable_shadows) {
@@ -357,7 +368,7 @@ RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t l
     const size_t k = (size_t)light_slot * Q.capacity + sample;
     const int32_t org_shape = Q.l_shape[sample], org_tri = Q.l_tri[sample], shape0 = Q.occ_shape[k];
     const float t0 = 1.0f;  // Hit::to_light; a sample whose own primitive blocks the light is not traced at all
-    const double px = Q.l_p[0][sample], py = Q.l_p[1][sample], pz = Q.l_p[2][sample];
+    const double px = RT_STREAM_LD(Q.l_p[0][sample]), py = RT_STREAM_LD(Q.l_p[1][sample]), pz = RT_STREAM_LD(Q.l_p[2][sample]);
     const RtLight &light = S.lights[S.point_lights[light_slot]];
     r.org_shape = org_shape;
     r.org_tri = org_tri;
@@ -418,9 +429,9 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
                            uint32_t sample) {
     const int32_t shape = Q.l_shape[sample];
     if (shape < 0) return false;
-    const D3 p = D3{Q.l_p[0][sample], Q.l_p[1][sample], Q.l_p[2][sample]};
-    const D3 n = D3{Q.l_n[0][sample], Q.l_n[1][sample], Q.l_n[2][sample]};
-    const D3 d = D3{Q.l_d[0][sample], Q.l_d[1][sample], Q.l_d[2][sample]};
+    const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+    const D3 n = D3{RT_STREAM_LD(Q.l_n[0][sample]), RT_STREAM_LD(Q.l_n[1][sample]), RT_STREAM_LD(Q.l_n[2][sample])};
+    const D3 d = D3{RT_STREAM_LD(Q.l_d[0][sample]), RT_STREAM_LD(Q.l_d[1][sample]), RT_STREAM_LD(Q.l_d[2][sample])};
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
     const bool want_ids = ids.shadow_shape || ids.shadow_tri;
     const size_t gs = want_ids ? global_sample(B, sample) : 0;
