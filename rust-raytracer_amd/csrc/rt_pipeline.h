@@ -289,8 +289,8 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         RT_STREAM_ST(Q.l_p[0][sample], p.x); RT_STREAM_ST(Q.l_p[1][sample], p.y); RT_STREAM_ST(Q.l_p[2][sample], p.z);
         RT_STREAM_ST(Q.l_n[0][sample], n.x); RT_STREAM_ST(Q.l_n[1][sample], n.y); RT_STREAM_ST(Q.l_n[2][sample], n.z);
         RT_STREAM_ST(Q.l_d[0][sample], d.x); RT_STREAM_ST(Q.l_d[1][sample], d.y); RT_STREAM_ST(Q.l_d[2][sample], d.z);
-        Q.l_shape[sample] = shape;
-        Q.l_tri[sample] = gtri;
+        RT_STREAM_ST(Q.l_shape[sample], shape);
+        RT_STREAM_ST(Q.l_tri[sample], gtri);
         if (!S.disable_shadows) {
             // Hit::to_light (hit_struct.rs:29-39) against the primitive the shadow ray starts on
             for (int ls = 0; ls < S.n_point_lights; ++ls) {
@@ -298,7 +298,7 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
                 double st = 0.0;
                 const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, st);
                 const size_t k = (size_t)ls * Q.capacity + (size_t)sample;
-                Q.occ_shape[k] = self ? shape : -1;
+                RT_STREAM_ST(Q.occ_shape[k], self ? shape : -1);
                 if (self) {  // rare; the other two arrays are only read where occ_shape says "blocked"
                     Q.occ_t[k] = (float)st;
                     Q.occ_tri[k] = -1;
@@ -366,7 +366,7 @@ RT_HD bool shadow_setup(const RtSceneView &S, const RtBuffers &Q, uint32_t light
 // round trip to memory after the other.
 RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t light_slot, uint32_t sample, RaySetup &r) {
     const size_t k = (size_t)light_slot * Q.capacity + sample;
-    const int32_t org_shape = Q.l_shape[sample], org_tri = Q.l_tri[sample], shape0 = Q.occ_shape[k];
+    const int32_t org_shape = RT_STREAM_LD(Q.l_shape[sample]), org_tri = RT_STREAM_LD(Q.l_tri[sample]), shape0 = RT_STREAM_LD(Q.occ_shape[k]);
     const float t0 = 1.0f;  // Hit::to_light; a sample whose own primitive blocks the light is not traced at all
     const double px = RT_STREAM_LD(Q.l_p[0][sample]), py = RT_STREAM_LD(Q.l_p[1][sample]), pz = RT_STREAM_LD(Q.l_p[2][sample]);
     const RtLight &light = S.lights[S.point_lights[light_slot]];
@@ -381,7 +381,7 @@ RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t l
 
 RT_HD void shadow_store(const RtBuffers &Q, uint32_t light_slot, uint32_t sample, int32_t shape, int32_t tri) {
     const size_t k = (size_t)light_slot * Q.capacity + sample;
-    Q.occ_shape[k] = shape;
+    RT_STREAM_ST(Q.occ_shape[k], shape);
     if (shape >= 0) Q.occ_tri[k] = tri;  // only read where occ_shape says "blocked"
 }
 
@@ -446,7 +446,7 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
         bool visible = true;
         if (!S.disable_shadows) {
             const size_t k = (size_t)slot * Q.capacity + sample;
-            const int32_t blocker = Q.occ_shape[k];
+            const int32_t blocker = RT_STREAM_LD(Q.occ_shape[k]);
             visible = blocker < 0;
             if (ids.shadow_shape) ids.shadow_shape[gs * (size_t)S.n_point_lights + slot] = blocker;
             if (ids.shadow_tri)
@@ -467,7 +467,7 @@ RT_HD void resolve_body(const RtBuffers &Q, const RtBatch &B, uint32_t lp, float
     const float *c = Q.color + (size_t)lp * spp * 3;
     float r = 0.0f, g = 0.0f, b = 0.0f;
     for (uint32_t k = 0; k < spp; ++k) {  // p-major, q-minor: k = p*n + q
-        r += c[k * 3 + 0];
+        r += c[k * 3 + 0];  // (plain loads: a thread walks through consecutive floats of the same lines)
         g += c[k * 3 + 1];
         b += c[k * 3 + 2];
     }
