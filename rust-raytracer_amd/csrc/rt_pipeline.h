@@ -147,8 +147,8 @@ RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls
 }
 
 RT_HD void queue_read_ray(const RtBuffers &Q, int which, uint32_t slot, D3 &o, D3 &d) {
-    o = D3{Q.q_o[which][0][slot], Q.q_o[which][1][slot], Q.q_o[which][2][slot]};
-    d = D3{Q.q_d[which][0][slot], Q.q_d[which][1][slot], Q.q_d[which][2][slot]};
+    o = D3{RT_STREAM_LD(Q.q_o[which][0][slot]), RT_STREAM_LD(Q.q_o[which][1][slot]), RT_STREAM_LD(Q.q_o[which][2][slot])};
+    d = D3{RT_STREAM_LD(Q.q_d[which][0][slot]), RT_STREAM_LD(Q.q_d[which][1][slot]), RT_STREAM_LD(Q.q_d[which][2][slot])};
 }
 
 // ---- trace (closest): render.rs:70 / perfect_mirror.rs:27.
@@ -335,12 +335,12 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
 
 RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const MirrorTmp &tmp) {
     const int which = (bounce + 1) & 1;
-    Q.q_o[which][0][slot] = tmp.p.x; Q.q_o[which][1][slot] = tmp.p.y; Q.q_o[which][2][slot] = tmp.p.z;
-    Q.q_d[which][0][slot] = tmp.d.x; Q.q_d[which][1][slot] = tmp.d.y; Q.q_d[which][2][slot] = tmp.d.z;
-    Q.q_sample[which][slot] = tmp.sample;
-    Q.q_org_shape[which][slot] = tmp.shape;
-    Q.q_org_tri[which][slot] = tmp.tri;
-    Q.q_self_t[which][slot] = tmp.self_t;
+    RT_STREAM_ST(Q.q_o[which][0][slot], tmp.p.x); RT_STREAM_ST(Q.q_o[which][1][slot], tmp.p.y); RT_STREAM_ST(Q.q_o[which][2][slot], tmp.p.z);
+    RT_STREAM_ST(Q.q_d[which][0][slot], tmp.d.x); RT_STREAM_ST(Q.q_d[which][1][slot], tmp.d.y); RT_STREAM_ST(Q.q_d[which][2][slot], tmp.d.z);
+    RT_STREAM_ST(Q.q_sample[which][slot], tmp.sample);
+    RT_STREAM_ST(Q.q_org_shape[which][slot], tmp.shape);
+    RT_STREAM_ST(Q.q_org_tri[which][slot], tmp.tri);
+    RT_STREAM_ST(Q.q_self_t[which][slot], tmp.self_t);
 }
 
 // ---- trace (shadow): light/point.rs:30-37.  Work item = (point light slot, local sample).
