@@ -261,6 +261,8 @@ def test_other_workloads_match_oracle_at_full_size(rt, backend, scene_path, name
     im, idm = parity.assert_parity(fb.pixels, ids, ref_fb, ref_ids, occlusion_only=True, label=name + " 1000^2")
     print(name, "1000^2 parity:", im, idm)
     assert abs(stats.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
+    again, _, again_stats = dev.render(3)  # queue appends and compaction leave no trace of their order
+    assert np.array_equal(again.pixels, fb.pixels) and again_stats.total_rays() == stats.total_rays()
     dev.close()
 
 
