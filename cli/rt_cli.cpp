@@ -15,6 +15,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../include/rt_hip.h"
 
 namespace {
@@ -142,6 +144,13 @@ int main(int argc, char **argv) {
     const uint32_t W = scene->image_width, H = scene->image_height;
     std::vector<float> fb((size_t)W * H * 3);
     RtStats st;
+    // main.rs:86-100 advances a progress bar from per_pixel_cb; here the count arrives once per
+    // finished batch of tiles (shown only on a terminal)
+    if (isatty(2))
+        ra.progress = [](uint64_t done, uint64_t total, void *) {
+            std::fprintf(stderr, "\rRendering: %3.0f %%", total ? 100.0 * (double)done / (double)total : 100.0);
+            if (done == total) std::fprintf(stderr, "\n");
+        };
     rc = rt_render(be, ds, &ra, fb.data(), nullptr, &st);
     int exit_code = 0;
     if (rc != RT_OK) {
