@@ -180,6 +180,35 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
     dev.close()
 
 
+@pytest.mark.parametrize("n,tile", [(1, 40), (2, 32), (4, 40), (5, 30), (8, 16), (3, 33), (2, 7), (1, 12)])
+def test_pixel_order_inside_tiles(rt, backend, scene_path, n, tile):
+    """Inside a tile the pixels are worked in blocks sized to the samples per pixel (8x8 pixels at one
+    sample, 4x2 at nine, single pixels at 64) when the block divides the tile, row by row otherwise.
+    Whatever the order, every pixel is rendered exactly once and lands where it belongs -- also in
+    the compact tile layout of a partitioned frame."""
+    import torch
+
+    W, H = 150, 100
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=3)
+    dev = backend.upload(scene)
+    ref_fb, ref_ids, _ = oracle_lib.render(scene, n, want_ids=True)
+    fb, ids, _ = dev.render(n, want_ids=True, tile=(tile, tile))
+    assert np.array_equal(ids.primary_shape, ref_ids.primary_shape)
+    assert parity.image_metrics(fb.pixels, ref_fb)["lsb1_fraction"] >= 0.999
+    a = dev.render_args(n, tile=(tile, tile), part=(0, 2))
+    _, _, stride = dev.partition_info(a)
+    gathered = torch.zeros(2 * stride * tile * tile * 3, dtype=torch.float32, device="cuda")
+    out = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(2):
+        a = dev.render_args(n, tile=(tile, tile), part=(p, 2))
+        dev.render_device(a, gathered.data_ptr() + p * stride * tile * tile * 3 * 4)
+    dev.untile_device(a, gathered.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(H, W, 3), fb.pixels)
+    dev.close()
+
+
 def test_frames_in_flight_on_several_backends(rt, backend, scene_path):
     """Four backends on one GPU, each with its own stream, render different frames at the same time
     with no host synchronisation in between (what the benchmark does).  Every frame must equal the
