@@ -32,8 +32,9 @@ extern "C" {
 #define RT_OK 0
 #define RT_ERR_INVALID (-1)     /* bad argument, or a scene the reference rejects with Err */
 #define RT_ERR_PARSE (-2)       /* malformed JSON / OBJ (scene/mod.rs:388) */
-#define RT_ERR_UNSUPPORTED (-3) /* the reference panics here (unimplemented!()), or the feature
-                                   has no deterministic definition (thread_rng) */
+#define RT_ERR_UNSUPPORTED (-3) /* the reference panics here (unimplemented!()), or a limit of this
+                                   library (GGXMirror beyond recursion depth 16, trees too deep
+                                   for the LDS traversal stack, an image format other than PNG) */
 #define RT_ERR_DEVICE (-4)      /* HIP runtime failure */
 #define RT_ERR_IO (-5)          /* file could not be read */
 
