@@ -207,6 +207,31 @@ class RtStats(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A PyTorch wheel bundles a HIP runtime of its own (torch/lib/libamdhip64.so, same soname as the
+    system's).  A process must hold ONE runtime: if librt_hip.so is loaded first it brings in the
+    system's, and torch, imported afterwards, finds no GPU.  So when torch is installed but not yet
+    imported, its copy is loaded first and librt_hip.so binds to it, exactly as when torch is imported
+    first.  Programs without torch (rt-cli) use the system runtime."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Loads librt_hip.so (built in-tree by `make -C rust-raytracer_amd/csrc`)."""
     global _lib
@@ -214,6 +239,7 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError(RT_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}`")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rt_last_error.restype = C.c_char_p
