@@ -417,7 +417,7 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
     if (!std::getenv("RT_PIXEL_BLOCK") || std::atoi(std::getenv("RT_PIXEL_BLOCK")) != 0) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
     const long n_samples = (long)B.n_pixels * spp;
     // rays: camera rays, or shadow rays from the camera rays' hit points
-    struct R { D3 o, d; float tmin, tmax; int32_t os, ot; bool anyhit; };
+    struct R { D3 o, d; float tmin, tmax; int32_t os, ot; bool anyhit; uint32_t i, j; };
     std::vector<R> rays;
     VecStack stk; stk.v.assign((size_t)S.stack_depth + 2, 0);
     for (long ls = 0; ls < n_samples; ++ls) {
@@ -426,7 +426,7 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
         const uint32_t pq = (uint32_t)(ls % spp);
         D3 o, d;
         camera_ray(S.camera, i, j, ((double)(pq / n) + 0.5) / (double)n, ((double)(pq % n) + 0.5) / (double)n, o, d);
-        if (light < 0) { rays.push_back(R{o, d, 1.0f, INFINITY, -1, -1, false}); continue; }
+        if (light < 0) { rays.push_back(R{o, d, 1.0f, INFINITY, -1, -1, false, i, j}); continue; }
         FastTrav st; bool overflow = false;
         fast_begin(S, st, stk, o, d, INFINITY, -1, -1, -1);
         while (fast_step<VecStack, false>(S, st, stk, 1.0f, S.stack_depth, overflow)) {}
@@ -435,10 +435,13 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
         if (st_ != RT_SHADER_LAMBERTIAN && st_ != RT_SHADER_BLINN_PHONG) continue;
         const D3 p = o + d * (double)st.t;
         const D3 lp = d3(S.lights[S.point_lights[light]].position);
-        rays.push_back(R{p, lp - p, 1e-6f, 1.0f, st.shape, st.tri, true});
+        rays.push_back(R{p, lp - p, 1e-6f, 1.0f, st.shape, st.tri, true, i, j});
     }
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     std::vector<int32_t> vn, vt, un, ut;
+    // RT_WAVE_DUMP=<file>: one record of six uint32 per wave (union nodes, longest lane's nodes, union
+    // triangles, longest lane's triangles, pixel of the first ray)
+    FILE *dump = std::getenv("RT_WAVE_DUMP") ? std::fopen(std::getenv("RT_WAVE_DUMP"), "wb") : nullptr;
     for (size_t w0 = 0; w0 + 64 <= rays.size(); w0 += 64) {
         un.clear(); ut.clear();
         size_t maxn = 0, maxt = 0, sumn = 0, sumt = 0;
@@ -460,7 +463,12 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
         std::sort(ut.begin(), ut.end()); ut.erase(std::unique(ut.begin(), ut.end()), ut.end());
         acc[0] += 1; acc[1] += (double)un.size(); acc[2] += (double)maxn; acc[3] += (double)sumn / 64.0;
         acc[4] += (double)ut.size(); acc[5] += (double)maxt; acc[6] += (double)sumt / 64.0;
+        if (dump) {
+            const uint32_t rec[6] = {(uint32_t)un.size(), (uint32_t)maxn, (uint32_t)ut.size(), (uint32_t)maxt, rays[w0].i, rays[w0].j};
+            std::fwrite(rec, sizeof(rec), 1, dump);
+        }
     }
+    if (dump) std::fclose(dump);
     for (int k = 0; k < 7; ++k) out[k] = acc[k];
     return 0;
 }
