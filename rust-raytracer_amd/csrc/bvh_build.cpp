@@ -340,6 +340,19 @@ void fill_payload(const RtShape &s, float f[12]) {
 
 }  // namespace
 
+// By how much a box of zero thickness is widened on each side in the fast mode's trees: 1e-5 of
+// the largest extent or coordinate of the bounds it lives in.
+static double flat_pad_for(const double bmin[3], const double bmax[3]) {
+    double pad = 0.0;
+    for (int c = 0; c < 3; ++c)
+        if (bmin[c] <= bmax[c] && std::isfinite(bmin[c]) && std::isfinite(bmax[c]))
+            pad = std::fmax(pad, std::fmax(bmax[c] - bmin[c], std::fmax(std::fabs(bmin[c]), std::fabs(bmax[c]))));
+    return pad > 0.0 ? pad * 1e-5 : 1e-5;
+}
+
+// 2 * 24 levels hold 2^24 triangles even when every split is 1 : 3; beyond that the mesh keeps the reference's tree
+static const int kMaxFastMeshDepth = 48;
+
 Tree build_tree_sah(std::vector<BuildItem> items, size_t max_leaf) {
     Tree tree;
     if (items.empty()) return tree;
@@ -367,6 +380,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
 
     // ---- one tree per mesh (geometry/mesh.rs:39-59)
     uint64_t tri_total = 0;
+    std::vector<double> mesh_pad;  // by how much a flat box of the fast mode's mesh tree is widened
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
         const RtMesh &mesh = scene.meshes[m];
         if (mesh.n_triangles == 0 || !mesh.vertices) return "mesh without triangles";
@@ -384,7 +398,45 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
             }
             it.id = (int32_t)i;
         }
-        out.blas.push_back(build_tree(std::move(items)));
+        out.blas.push_back(build_tree(items));
+        // The fast mode's tree of the same mesh, split by surface area (leaves of up to 4).  The
+        // median split leaves a few regions where a ray that runs along the surface passes through
+        // hundreds of overlapping boxes (bunny frame: the worst wave visits 304 nodes against 16 on
+        // average); those rays set the run time of small launches.  As for the scene-level tree, it
+        // holds exactly the triangles the reference can reach -- those of reference leaves whose box
+        // is not flat (bbox.rs:89,104,119) -- and its own flat boxes are widened.  RT_MESH_SAH=0 keeps
+        // the reference's tree in fast mode too, for comparison; a tree too deep for the traversal
+        // stack's budget (a degenerate mesh) is dropped the same way.
+        bool own = true;
+        if (const char *e = std::getenv("RT_MESH_SAH")) own = std::atoi(e) != 0;
+        Tree fast;
+        double pad = 0.0;
+        if (own) {
+            const Tree &ref = out.blas.back();
+            std::vector<BuildItem> reachable;
+            for (const TreeNode &n : ref.nodes) {
+                if (n.count == 0) continue;
+                if (!(n.bmin[0] < n.bmax[0]) || !(n.bmin[1] < n.bmax[1]) || !(n.bmin[2] < n.bmax[2])) continue;
+                for (uint32_t k = 0; k < n.count; ++k) reachable.push_back(items[(size_t)ref.order[n.first + k]]);
+            }
+            std::sort(reachable.begin(), reachable.end(), [](const BuildItem &a, const BuildItem &b) { return a.id < b.id; });
+            pad = flat_pad_for(ref.nodes[0].bmin, ref.nodes[0].bmax);
+            if (!reachable.empty()) fast = build_tree_sah(std::move(reachable), 4);
+            if (fast.inner_depth > kMaxFastMeshDepth) fast = Tree();
+        }
+        out.mesh_tri_base_fast.push_back(out.mesh_tri_base.back());  // bases of the copies are set below
+        out.blas_fast.push_back(std::move(fast));
+        mesh_pad.push_back(pad);
+    }
+    for (uint32_t m = 0; m < scene.n_meshes; ++m) {
+        if (out.blas_fast[m].nodes.empty()) continue;
+        const uint64_t count = out.blas_fast[m].order.size();
+        if (tri_total + count >= (1ull << 26)) {  // no room for a second copy: keep the reference's tree
+            out.blas_fast[m] = Tree();
+            continue;
+        }
+        out.mesh_tri_base_fast[m] = tri_total;
+        tri_total += count;
     }
 
     // ---- scene-level tree (scene/mod.rs:699-700)
@@ -425,11 +477,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
             }
         }
     }
-    double flat_pad = 0.0;
-    for (int c = 0; c < 3; ++c)
-        if (scene_min[c] <= scene_max[c])
-            flat_pad = std::fmax(flat_pad, std::fmax(scene_max[c] - scene_min[c], std::fmax(std::fabs(scene_min[c]), std::fabs(scene_max[c]))));
-    flat_pad = flat_pad > 0.0 ? flat_pad * 1e-5 : 1e-5;
+    const double flat_pad = flat_pad_for(scene_min, scene_max);
     std::sort(reachable.begin(), reachable.end(), [](const BuildItem &a, const BuildItem &b) { return a.id < b.id; });
     const bool own_fast_tree = !reachable.empty();
     if (own_fast_tree) out.tlas_fast = build_tree_sah(std::move(reachable), 2);
@@ -438,28 +486,39 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
     out.tlas_root = emit_with_header(out.tlas, 0, out.nodes);
     const uint32_t fast_base = (uint32_t)out.tlas.order.size();  // the fast tree's primitives follow the reference tree's
     out.tlas_root_fast = own_fast_tree ? emit_with_header(out.tlas_fast, fast_base, out.nodes, flat_pad) : out.tlas_root;
-    std::vector<int32_t> blas_root(scene.n_meshes);
-    int blas_depth = 0;
+    std::vector<int32_t> blas_root(scene.n_meshes), blas_root_fast(scene.n_meshes);
+    int blas_depth = 0, blas_depth_fast = 0;
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
         blas_root[m] = emit_with_header(out.blas[m], (uint32_t)out.mesh_tri_base[m], out.nodes);
         blas_depth = std::max(blas_depth, out.blas[m].inner_depth);
     }
+    for (uint32_t m = 0; m < scene.n_meshes; ++m) {
+        blas_root_fast[m] = blas_root[m];
+        blas_depth_fast = std::max(blas_depth_fast, out.blas[m].inner_depth);
+        if (!own_fast_tree || out.blas_fast[m].nodes.empty()) continue;  // only the fast scene-level tree's primitives point here
+        blas_root_fast[m] = emit_with_header(out.blas_fast[m], (uint32_t)out.mesh_tri_base_fast[m], out.nodes, mesh_pad[m]);
+        blas_depth_fast = std::max(blas_depth_fast, out.blas_fast[m].inner_depth);
+    }
     // pushes on one path: one per inner node with two live children, plus, when a
     // mesh or instance is entered from a leaf, the rest of that leaf and the exit marker
     if (out.nodes.size() >= (1u << 25)) return "too many tree nodes for a 31-bit byte offset";
-    out.stack_depth = std::max(out.tlas.inner_depth, out.tlas_fast.inner_depth) + 2 + blas_depth + 1;
+    out.stack_depth = out.tlas.inner_depth + 2 + blas_depth + 1;
+    out.stack_depth_fast = std::max(out.tlas.inner_depth, out.tlas_fast.inner_depth) + 2 + blas_depth_fast + 1;
 
     // ---- triangles in leaf order
     out.tris.resize((size_t)tri_total);
     out.tri_xf.resize((size_t)tri_total);
     out.verts64.assign((size_t)tri_total * 12, 0.0);
+    for (uint32_t copy = 0; copy < 2; ++copy)
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
         const RtMesh &mesh = scene.meshes[m];
-        const Tree &t = out.blas[m];
+        const Tree &t = copy == 0 ? out.blas[m] : out.blas_fast[m];
+        const size_t base = (size_t)(copy == 0 ? out.mesh_tri_base[m] : out.mesh_tri_base_fast[m]);
+        if (copy == 1 && t.nodes.empty()) continue;
         for (size_t k = 0; k < t.order.size(); ++k) {
             const int32_t orig = t.order[k];
             const double *v = mesh.vertices + (size_t)orig * 9;
-            RtTri &tri = out.tris[(size_t)out.mesh_tri_base[m] + k];
+            RtTri &tri = out.tris[base + k];
             for (int c = 0; c < 3; ++c) {
                 tri.a[c] = (float)v[c];
                 tri.ab[c] = (float)(v[c] - v[3 + c]);
@@ -468,10 +527,10 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
             tri.orig = orig;
             tri.mesh = (int32_t)m;
             tri._pad = 0;
-            triangle_map(v, out.tri_xf[(size_t)out.mesh_tri_base[m] + k]);
+            triangle_map(v, out.tri_xf[base + k]);
             // f64 vertices and the unit normal normalize((b - a) x (c - a)) of triangle.rs:22, evaluated
             // with the operation order of the device's D3 helpers (no contraction on either side)
-            double *w = &out.verts64[((size_t)out.mesh_tri_base[m] + k) * 12];
+            double *w = &out.verts64[(base + k) * 12];
             std::memcpy(w, v, 9 * sizeof(double));
             const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
             const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
@@ -487,6 +546,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
     for (size_t k = 0; k < n_tprims; ++k) {
         const int32_t id = k < out.tlas.order.size() ? out.tlas.order[k] : out.tlas_fast.order[k - out.tlas.order.size()];
         const RtShape &s = scene.shapes[id];
+        const std::vector<int32_t> &mesh_root = k < out.tlas.order.size() ? blas_root : blas_root_fast;
         RtTPrim &p = out.tprims[k];
         std::memset(&p, 0, sizeof(p));
         p.type = s.type;
@@ -494,14 +554,14 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         p.blas_root = -1;
         p.proto_type = -1;
         if (s.type == RT_SHAPE_MESH) {
-            p.blas_root = blas_root[(size_t)s.mesh];
+            p.blas_root = mesh_root[(size_t)s.mesh];
         } else if (s.type == RT_SHAPE_INSTANCE) {
             for (int r = 0; r < 3; ++r)
                 for (int c = 0; c < 4; ++c) out.tprim_xf[k * 12 + (size_t)r * 4 + c] = (float)s.inv_transform[r * 4 + c];
             const RtShape &proto = scene.protos[s.proto];
             p.proto_type = proto.type;
             if (proto.type == RT_SHAPE_MESH) {
-                p.blas_root = blas_root[(size_t)proto.mesh];
+                p.blas_root = mesh_root[(size_t)proto.mesh];
                 // world box of the instance (instance.rs:42), for the fast mode's pre-test
                 const double bmin[3] = {s.bbox_min.x, s.bbox_min.y, s.bbox_min.z};
                 const double bmax[3] = {s.bbox_max.x, s.bbox_max.y, s.bbox_max.z};

@@ -43,15 +43,19 @@ struct FlatScene {
     std::vector<RtTri> tris;
     std::vector<RtTriXf> tri_xf;          // same order as `tris`
     std::vector<uint64_t> mesh_tri_base;  // first entry of `tris` / `verts64` triangle per mesh
+    std::vector<uint64_t> mesh_tri_base_fast;  // the same for the fast mode's copy of the mesh (leaf order of
+                                          // `blas_fast`); equal to mesh_tri_base where the mesh has no such copy
     std::vector<double> verts64;          // 12 doubles per triangle, same order as `tris`: a, b, c and the
                                           // unit normal Triangle::new stores (triangle.rs:22)
     int32_t tlas_root = 0;                // header node of the scene-level tree
     int32_t tlas_root_fast = 0;           // header node of the fast mode's scene-level tree (its leaves index
                                           // the second part of `tprims`)
-    int stack_depth = 0;                  // traversal-stack entries a ray can need at most
+    int stack_depth = 0;                  // traversal-stack entries a ray can need at most in the reference's trees
+    int stack_depth_fast = 0;             // the same in the fast mode's trees
     Tree tlas;                            // kept for structural tests
     Tree tlas_fast;
     std::vector<Tree> blas;
+    std::vector<Tree> blas_fast;          // the fast mode's mesh trees; empty tree = the mesh keeps the reference's
 };
 
 // Returns "" on success, else a message.

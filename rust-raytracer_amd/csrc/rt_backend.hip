@@ -577,8 +577,8 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     if (tile_samples > (1ull << 30)) return rt::set_error(RT_ERR_INVALID, "tile too large");
     if (ds->view.recursion_depth > 30) return rt::set_error(RT_ERR_INVALID, "recursion depth above 30");
 
-    const size_t lds_bytes =
-        (size_t)(std::max(ds->view.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
+    const int mode_stack_depth = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view.stack_depth : ds->view_fast.stack_depth;
+    const size_t lds_bytes = (size_t)(std::max(mode_stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
     if (lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
 
     RT_HIP(hipSetDevice(be->device));
@@ -883,6 +883,7 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
     V.stack_depth = flat.stack_depth;
     ds->view_fast = V;
     ds->view_fast.tlas_root = flat.tlas_root_fast;
+    ds->view_fast.stack_depth = flat.stack_depth_fast;
     ds->width = scene->image_width;
     ds->height = scene->image_height;
     ds->n_point_lights = (uint32_t)point_lights.size();
@@ -1122,7 +1123,8 @@ extern "C" int rt_trace_rays(RtBackend *be, const RtDeviceScene *ds, uint64_t n,
         hipMemcpy(d_tmax, tmax, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(d_over, 0, sizeof(uint32_t)) != hipSuccess)
         return bail(rt::set_error(RT_ERR_DEVICE, "hipMemcpy to device failed"));
-    const size_t lds_bytes = (size_t)(std::max(ds->view.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
+    const int mode_stack_depth = mode == RT_MODE_REFERENCE_ORDER ? ds->view.stack_depth : ds->view_fast.stack_depth;
+    const size_t lds_bytes = (size_t)(std::max(mode_stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
     if (lds_bytes > 64 * 1024) return bail(rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack"));
     if (mode == RT_MODE_REFERENCE_ORDER)
         hipLaunchKernelGGL((k_trace_user<false, true>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);

@@ -32,9 +32,26 @@ def degenerate_obj(path):
                 "f 1 2 3\nf 1 3 4\nf 5 6 7\nf 8 9 10\n")
 
 
+def half_flat_obj(path):
+    """Sixteen triangles: eight in the plane z = 0 at x < 0, eight tilted ones at x > 0.  The reference's
+    tree (median split on x, then y, leaves of four) puts the coplanar ones into leaves whose boxes have
+    no thickness, and such a box is never entered (bbox.rs:89,104,119): that half of the mesh is
+    invisible in the reference, and must be in every mode here."""
+    v, f = [], []
+    for half, (x0, tilt) in enumerate([(-1.6, 0.0), (0.4, 0.35)]):
+        for q in range(4):
+            xa, ya = x0 + 0.6 * (q % 2), -0.6 + 0.6 * (q // 2)
+            base = len(v)
+            v += [(xa, ya, 0.0), (xa + 0.55, ya, tilt * 0.5), (xa + 0.55, ya + 0.55, tilt), (xa, ya + 0.55, tilt * 0.5)]
+            f += [(base + 1, base + 2, base + 3), (base + 1, base + 3, base + 4)]
+    with open(path, "w") as out:
+        out.write("o m\n" + "".join(f"v {a} {b} {c}\n" for a, b, c in v) + "".join(f"f {a} {b} {c}\n" for a, b, c in f))
+
+
 def scenes(tmp_dir):
     obj = os.path.join(tmp_dir, "degenerate.obj")
     degenerate_obj(obj)
+    half_flat_obj(os.path.join(tmp_dir, "half_flat.obj"))
     out = {
         "no_lights": (_scene(shape=BALLS), 64, 48, 2),
         "ambient_only": (_scene(shape=BALLS, light=[AMBIENT]), 64, 48, 2),
@@ -49,6 +66,8 @@ def scenes(tmp_dir):
                                       BALLS[2]], light=[POINT]), 80, 60, 2),
         "degenerate_mesh": (_scene(shape=[{"_name": "mesh", "_type": "mesh", "shader": "bp", "file": "degenerate.obj"}, BALLS[2]],
                                    light=[POINT, AMBIENT]), 96, 72, 2),
+        "half_flat_mesh": (_scene(shape=[{"_name": "mesh", "_type": "mesh", "shader": "bp", "file": "half_flat.obj"}, BALLS[2]],
+                                  light=[POINT, AMBIENT]), 96, 72, 2),
         "scaled_instances": (_scene(
             instance=[{"_name": "proto", "_type": "mesh", "shader": "lam", "file": "degenerate.obj"},
                       {"_name": "ball", "_type": "sphere", "shader": "lam", "center": "0 0 0", "radius": 1.0}],
@@ -63,7 +82,7 @@ def scenes(tmp_dir):
 
 
 NAMES = ["no_lights", "ambient_only", "one_shape", "one_pixel", "wide_aspect", "odd_size_many_samples", "camera_inside_box",
-         "mirror_pair", "degenerate_mesh", "scaled_instances"]
+         "mirror_pair", "degenerate_mesh", "half_flat_mesh", "scaled_instances"]
 
 
 def ggx_scene(roughness=0.25, samples=3, mirror_type=None):

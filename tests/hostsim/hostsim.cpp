@@ -92,6 +92,7 @@ std::string make_view(const RtScene &scene, HostScene &hs) {
     V.stack_depth = hs.flat.stack_depth;
     hs.view_fast = V;
     hs.view_fast.tlas_root = hs.flat.tlas_root_fast;
+    hs.view_fast.stack_depth = hs.flat.stack_depth_fast;
     for (uint32_t s = 0; s < scene.n_shapes; ++s) {
         const int32_t t = scene.shaders[scene.shapes[s].shader].type;
         hs.has_mirror = hs.has_mirror || t == RT_SHADER_PERFECT_MIRROR;
@@ -329,18 +330,20 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
     HostScene hs;
     if (!make_view(*scene, hs).empty()) return -1;
     VecStack stk;
-    stk.v.assign((size_t)std::max(hs.view.stack_depth, 1), 0);
+    stk.v.assign((size_t)std::max(std::max(hs.view.stack_depth, hs.view_fast.stack_depth), 1), 0);
     for (uint64_t r = 0; r < n; ++r) {
         HitF hit;
         const D3 ro{o[r * 3], o[r * 3 + 1], o[r * 3 + 2]}, rd{d[r * 3], d[r * 3 + 1], d[r * 3 + 2]};
         bool ok;
         int32_t os = org_shape ? org_shape[r] : -1, ot = -1;
         if (os >= 0 && org_tri && org_tri[r] >= 0) {
-            // file-order index -> leaf-order index of that shape's mesh
+            // file-order index -> leaf-order index of that shape's mesh (in the copy the mode traverses)
             const RtShape &sh = scene->shapes[os];
             const int32_t mesh = sh.type == RT_SHAPE_INSTANCE ? scene->protos[sh.proto].mesh : sh.mesh;
-            const uint64_t base = hs.flat.mesh_tri_base[(size_t)mesh];
-            for (uint64_t k = 0; k < scene->meshes[mesh].n_triangles; ++k)
+            const uint64_t base = mode == RT_MODE_REFERENCE_ORDER ? hs.flat.mesh_tri_base[(size_t)mesh] : hs.flat.mesh_tri_base_fast[(size_t)mesh];
+            const bool own_copy = mode != RT_MODE_REFERENCE_ORDER && !hs.flat.blas_fast[(size_t)mesh].nodes.empty();
+            const uint64_t count = own_copy ? hs.flat.blas_fast[(size_t)mesh].order.size() : scene->meshes[mesh].n_triangles;
+            for (uint64_t k = 0; k < count; ++k)
                 if (hs.flat.tris[(size_t)(base + k)].orig == org_tri[r]) ot = (int32_t)(base + k);
         }
         hit.t = (float)tmax[r];
@@ -376,14 +379,16 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
 }
 
 // Structure of the flattened trees, for comparison with the oracle's own build:
-// which = -1 scene-level (reference order), -2 the fast mode's scene-level tree, else mesh index.
+// which = -1 scene-level (reference order), -2 the fast mode's scene-level tree, -3 - m the fast
+// mode's tree of mesh m (no nodes if that mesh keeps the reference's), else mesh index.
 // Same conventions as oracle_bvh_dump.
 extern "C" int64_t hostsim_bvh_dump(const RtScene *scene, int32_t which, int64_t cap_nodes, int64_t cap_prims,
                                     int32_t *kinds_out, int32_t *prims_out, double *boxes_out, int64_t *n_prims_out,
                                     int32_t *stack_depth_out) {
     rt::FlatScene flat;
     if (!rt::flatten_scene(*scene, flat).empty()) return -2;
-    const rt::Tree &t = which == -2 ? flat.tlas_fast : (which < 0 ? flat.tlas : flat.blas[(size_t)which]);
+    const rt::Tree &t = which <= -3 ? flat.blas_fast[(size_t)(-3 - which)]
+                                     : (which == -2 ? flat.tlas_fast : (which < 0 ? flat.tlas : flat.blas[(size_t)which]));
     if ((int64_t)t.nodes.size() > cap_nodes || (int64_t)t.order.size() > cap_prims) return -1;
     for (size_t i = 0; i < t.nodes.size(); ++i) {
         kinds_out[i] = t.nodes[i].count ? (int32_t)t.nodes[i].count : -1;
@@ -392,7 +397,7 @@ extern "C" int64_t hostsim_bvh_dump(const RtScene *scene, int32_t which, int64_t
     }
     std::memcpy(prims_out, t.order.data(), t.order.size() * sizeof(int32_t));
     *n_prims_out = (int64_t)t.order.size();
-    if (stack_depth_out) *stack_depth_out = flat.stack_depth;
+    if (stack_depth_out) *stack_depth_out = which <= -2 ? flat.stack_depth_fast : flat.stack_depth;
     return (int64_t)t.nodes.size();
 }
 

@@ -77,11 +77,63 @@ def test_stack_depth_bounds_the_walk(rt, scene_path):
 
         sys.setrecursionlimit(10000)
         k_top, _, _, stack_depth = HS.bvh_dump(sc, -1)
-        k_fast, _, _, _ = HS.bvh_dump(sc, -2)  # the fast mode's own scene-level tree
-        need = max(depth_of(k_top), depth_of(k_fast))
+        k_fast, _, _, stack_depth_fast = HS.bvh_dump(sc, -2)  # the fast mode's own scene-level tree
         mesh = max([depth_of(HS.bvh_dump(sc, m)[0]) for m in range(sc.c.n_meshes)] or [0])
-        assert stack_depth >= need + mesh + 1
-        assert stack_depth <= need + mesh + 6  # and is not wastefully large (LDS stack rows)
+        assert stack_depth >= depth_of(k_top) + mesh + 1
+        assert stack_depth <= depth_of(k_top) + mesh + 6  # and is not wastefully large (LDS stack rows)
+        # the fast mode walks its own scene-level tree and, per mesh, its own tree if it has one
+        need = max(depth_of(k_top), depth_of(k_fast))
+        fast = [HS.bvh_dump(sc, -3 - m)[0] for m in range(sc.c.n_meshes)]
+        mesh_fast = max([depth_of(k) for k in fast if len(k)] + [mesh])
+        assert stack_depth_fast >= need + mesh_fast + 1
+        assert stack_depth_fast <= need + mesh_fast + 6
+
+
+def test_fast_mesh_trees_hold_the_reachable_triangles_once(rt, scene_path, tmp_path):
+    """The fast mode's mesh trees are split by surface area; they must hold exactly the triangles the
+    reference's tree can reach (those of its leaves whose box is not flat, bbox.rs:89,104,119), each
+    once, in leaves of at most four, every box inside its parent's, and the leaf boxes must contain
+    their triangles."""
+    import sys
+
+    import edge_scenes
+
+    sys.setrecursionlimit(10000)
+    text, data_dir, _, _, _ = edge_scenes.scenes(str(tmp_path))["degenerate_mesh"]
+    for sc in [rt.parse_scene_file(scene_path("bunny_small")), rt.parse_scene_file(scene_path("mixed_features")),
+               rt.parse_scene(text, data_dir)]:
+        assert sc.c.n_meshes > 0
+        for m in range(sc.c.n_meshes):
+            kinds, prims, boxes, _ = HS.bvh_dump(sc, -3 - m)
+            n_tri = int(sc.c.meshes[m].n_triangles)
+            assert len(kinds) > 0, "these meshes are expected to get a tree of their own"
+            k_ref, p_ref, b_ref, _ = HS.bvh_dump(sc, m)
+            reachable, pos = [], 0
+            for k, b in zip(k_ref.tolist(), b_ref):
+                if k < 0:
+                    continue
+                if (b[3:] > b[:3]).all():
+                    reachable += p_ref[pos:pos + k].tolist()
+                pos += k
+            assert sorted(prims.tolist()) == sorted(reachable)
+            assert max(k for k in kinds.tolist() if k > 0) <= 4
+            verts = np.ctypeslib.as_array(sc.c.meshes[m].vertices, shape=(n_tri, 3, 3))
+            at = [0]
+
+            def check(i):
+                if kinds[i] >= 0:
+                    tri = verts[prims[at[0]:at[0] + kinds[i]]].reshape(-1, 3)
+                    at[0] += kinds[i]
+                    assert (tri >= boxes[i][:3]).all() and (tri <= boxes[i][3:]).all()
+                    return i + 1
+                l = i + 1
+                r = check(l)
+                end = check(r)
+                for c in (l, r):
+                    assert (boxes[c][:3] >= boxes[i][:3]).all() and (boxes[c][3:] <= boxes[i][3:]).all()
+                return end
+
+            assert check(0) == len(kinds)
 
 
 def test_fast_scene_tree_holds_the_reachable_shapes(rt, scene_path, tmp_path):
