@@ -82,7 +82,11 @@ void rt_backend_destroy(RtBackend *backend);
 /* Flattens the scene into HBM: builds the top-level and per-mesh BVHs with the
  * reference's split rule (geometry/bvh.rs:36-87), linearises them, and uploads
  * fp32 traversal records plus the f64 originals.  Replaces the tree build that
- * parse_scene performs at scene/mod.rs:699-700 and geometry/mesh.rs:59. */
+ * parse_scene performs at scene/mod.rs:699-700 and geometry/mesh.rs:59.
+ * RT_MODE_REFERENCE_ORDER walks exactly these trees.  RT_MODE_FAST, whose results do
+ * not depend on the visiting order, walks surface-area trees of its own, built here
+ * over the shapes and triangles the reference's trees can reach (a leaf whose box
+ * has zero thickness is never entered, geometry/bbox.rs:89,104,119). */
 int rt_scene_upload(RtBackend *backend, const RtScene *scene, RtDeviceScene **dev_scene_out);
 void rt_scene_free(RtDeviceScene *dev_scene);
 
