@@ -84,6 +84,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # A frame cut into more than four parts leaves each GPU launches so small that a kernel lasts as
+    # long as its slowest wave, and a frame's chain of kernels (0.5-0.7 ms for a 1/8 frame alone) sets
+    # the pace: with HIP's default of four hardware queues at most four chains overlap.  Eight queues and
+    # eight frames in flight took the slowest 1/8 part from 0.184 to 0.177 ms per frame (and its spread
+    # over the parts from 0.163-0.184 to 0.165-0.177); for a whole, half or quarter frame four of each
+    # are as good or slightly better.  The variable is read when the HIP runtime starts, so it is set
+    # before torch is imported.
+    many_parts = int(os.environ.get("WORLD_SIZE", "1")) > 4
+    hw_queues = os.environ.get("RT_BENCH_HW_QUEUES", "8" if many_parts else "")
+    if hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = hw_queues
+
     import torch
     import torch.distributed as dist
 
@@ -118,7 +130,8 @@ def main():
     # overlaps the next frame's work instead of idling the GPU.  Measured on one MI355X for this
     # frame cut into 8 parts: 0.54 ms per part-frame with one frame in flight, 0.28 ms with four
     # (the whole frame: 1.82 -> 1.76 ms).
-    FLIGHTS = int(os.environ.get("RT_BENCH_FLIGHTS", "4"))  # frames in flight per GPU (3 to 8 measure within 2 % of each other, 2 is 9 % slower)
+    # frames in flight per GPU (whole frame: 3 to 8 measure within 2 % of each other, 2 is 9 % slower)
+    FLIGHTS = int(os.environ.get("RT_BENCH_FLIGHTS", "8" if many_parts else "4"))
     backends = [rt.Backend(local_rank) for _ in range(FLIGHTS)]
     t_up = time.perf_counter()
     devs = [be.upload(scene) for be in backends]
@@ -291,7 +304,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "traversal": args.mode, "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
-                       "frames_in_flight": FLIGHTS,
+                       "frames_in_flight": FLIGHTS, "hw_queues": int(hw_queues) if hw_queues else "runtime default",
                        "scene_upload_ms": upload_s * 1e3,
                        "kernel_split_from": "warm-up frames (fully instrumented); roofline duration from the timed frames"},
             "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / n_stat for k in range(len(rt.KERNEL_CLASSES))},
