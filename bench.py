@@ -63,6 +63,28 @@ def measured_traffic(workload, kernel_class):
         return None
 
 
+def measured_hbm_gbs(torch):
+    """What the box's HBM delivers to a plain streaming kernel, as a second denominator beside the
+    datasheet figure: the better of a device-to-device copy (read + write) and a triad a = b + s * c
+    (two reads + one write) over 1 GiB arrays, best of five runs each, in GB/s."""
+    n = 1 << 28  # floats
+    a, b, c = (torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3))
+    b.fill_(1.0)
+    c.fill_(2.0)
+    best = 0.0
+    for op, moved in ((lambda: a.copy_(b), 2), (lambda: torch.add(b, c, alpha=0.5, out=a), 3)):
+        op()
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            op()
+            e1.record()
+            e1.synchronize()
+            best = max(best, moved * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b, c
+    return best
+
+
 def cpu_baseline(rt, scene_name, depth, sample_px, n, threads):
     import oracle_lib
 
@@ -289,6 +311,11 @@ def main():
             alone_ms = k_ms[dom] / max(k_n[dom], 1)
             alone = bytes_per_launch / (alone_ms * 1e-3) / 1e9
             roofline["alone_on_the_gpu"] = {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS}
+            if world == 1:
+                torch.cuda.set_stream(torch.cuda.default_stream())
+                hbm = measured_hbm_gbs(torch)
+                roofline["peak_measured"] = hbm  # copy / triad on this box, GB/s
+                roofline["frac_of_measured"] = achieved / hbm
         out = {
             "metric": "rays/sec (all ray types), Stanford bunny 1000² spp9 d6, 1/2/4/8 GPUs",
             "value": value,
