@@ -82,6 +82,22 @@ def test_recursion_depth_limits_mirror_bounces(rt, scene_path):
         assert ids.bounces.max() <= depth
 
 
+def test_fast_mesh_trees_change_no_hit(rt, scene_path, monkeypatch):
+    """The fast mode's surface-area mesh trees against the reference's trees walked by the same fast
+    code (RT_MESH_SAH=0 at scene flattening): the same closest hits -- a tree only culls -- except
+    where two triangles tie in fp32 along a shared edge, and the same image."""
+    sc = rt.parse_scene_file(scene_path("bunny_small"), image_width=160, image_height=120, recursion_depth=4)
+    fb_a, ids_a, st_a = HS.render(sc, 2, mode=rt.RT_MODE_FAST)
+    monkeypatch.setenv("RT_MESH_SAH", "0")
+    fb_b, ids_b, st_b = HS.render(sc, 2, mode=rt.RT_MODE_FAST)
+    same = (ids_a.primary_shape == ids_b.primary_shape) & (ids_a.primary_tri == ids_b.primary_tri)
+    assert same.mean() >= 0.9999, same.mean()
+    assert np.array_equal(ids_a.shadow_shape >= 0, ids_b.shadow_shape >= 0) or \
+        ((ids_a.shadow_shape >= 0) == (ids_b.shadow_shape >= 0)).mean() >= 0.9999
+    assert parity.image_metrics(fb_a, fb_b)["max_abs_diff"] <= 1
+    assert st_a.total_rays() == st_b.total_rays()
+
+
 @pytest.mark.parametrize("parts", [2, 3])
 def test_partitioned_render_tiles_the_image(rt, scene_path, parts):
     """Each part renders only the tiles it owns; the parts are disjoint, cover the image, and their
