@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the render hot path: rays/s (camera + mirror + shadow rays).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A step is one render of the whole frame with the scene already resident in HBM.
 With N > 1 the frame is cut into interleaved tiles, rank r renders the tiles of
-part r into a compact device buffer, one RCCL gather brings the buffers to rank 0
-and a kernel there restores the image layout; total work is fixed, so scaling is
-"strong".  Rank 0 prints one JSON line.
+part r into a compact device buffer, an RCCL gather brings the buffers to rank 0
+(one gather for the frames in flight together) and a kernel there restores the
+image layout of every frame; total work is fixed, so scaling is "strong".  Rank 0
+prints one JSON line.
 """
 from __future__ import annotations
 
@@ -99,7 +100,7 @@ def cpu_baseline(rt, scene_name, depth, sample_px, n, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "reference"])
@@ -108,13 +109,15 @@ def main():
 
     # A frame cut into more than four parts leaves each GPU launches so small that a kernel lasts as
     # long as its slowest wave, and a frame's chain of kernels (0.5-0.7 ms for a 1/8 frame alone) sets
-    # the pace: with HIP's default of four hardware queues at most four chains overlap.  Eight queues and
-    # eight frames in flight took the slowest 1/8 part from 0.184 to 0.177 ms per frame (and its spread
-    # over the parts from 0.163-0.184 to 0.165-0.177); for a whole, half or quarter frame four of each
-    # are as good or slightly better.  The variable is read when the HIP runtime starts, so it is set
-    # before torch is imported.
+    # the pace: with HIP's default of four hardware queues at most four chains overlap.  Eight frames
+    # in flight on queues of their own took the slowest 1/8 part from 0.184 to 0.177 ms per frame.  The
+    # gather and un-tile streams need queues of their own as well: a stream that shares a hardware queue
+    # with a render stream holds up that stream's kernels whenever it waits for an event (rank 0's step
+    # with 8 queues for 11 streams: 0.25 ms per frame, with 32 queues: 0.19).  For a whole, half or
+    # quarter frame the runtime's default is as good or slightly better.  The variable is read when the
+    # HIP runtime starts, so it is set before torch is imported.
     many_parts = int(os.environ.get("WORLD_SIZE", "1")) > 4
-    hw_queues = os.environ.get("RT_BENCH_HW_QUEUES", "8" if many_parts else "")
+    hw_queues = os.environ.get("RT_BENCH_HW_QUEUES", "32" if many_parts else "")
     if hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = hw_queues
 
@@ -183,47 +186,70 @@ def main():
         def drain():
             pass
     else:
-        # Per flight: the part buffer this rank renders into and, on rank 0, the gather target.
+        # GROUP consecutive frames are gathered together: every rank renders its part of each into one
+        # buffer, ONE gather brings all of them to rank 0, and rank 0 restores the image layout frame
+        # by frame on a side stream.  Two groups alternate, so the gather and un-tiling of one overlap
+        # the renders of the other.  Measured on one MI355X with a one-rank RCCL group
+        # (tools/gather_host_cost.py: the gather degenerates to a local copy, so this is a lower bound),
+        # per 1/8 frame: render alone 0.169 ms; with a gather and an un-tile per frame 0.245 ms; per
+        # group of 8 frames 0.191 ms, of 16 frames 0.183 ms (of which the un-tile kernels are 0.010).
+        GROUP = 2 * FLIGHTS
         part_floats = stride * tile_floats
-        part = [torch.zeros(part_floats, dtype=torch.float32, device="cuda") for _ in range(FLIGHTS)]
-        gathered = [torch.zeros(world * part_floats, dtype=torch.float32, device="cuda") if rank == 0 else None
-                    for _ in range(FLIGHTS)]
-        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        part = [torch.zeros(GROUP * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        root = rank == 0
+        gathered = [torch.zeros(world * GROUP * part_floats, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
+        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if root else None
+        joiner = torch.cuda.Stream()     # waits for the frames of a group, then issues their gather
         side = torch.cuda.Stream()       # rank 0: waits for a gather and restores the image layout
-        pending = [None] * FLIGHTS       # the gather that last read part[b] / wrote gathered[b]
-        untiled = [None] * FLIGHTS       # event: gathered[b] has been consumed
+        sent = [None, None]              # event: the gather that read part[g] / wrote gathered[g] is done
+        untiled = [None, None]           # event: gathered[g] has been consumed
+
+        def flush(g, count):
+            """Gathers the first `count` frames of group g and, on rank 0, un-tiles them."""
+            for b in range(min(count, FLIGHTS)):
+                joiner.wait_stream(streams[b])
+            mine = part[g][: count * part_floats]
+            with torch.cuda.stream(joiner):
+                if staged:  # rehearsal on one GPU: through host memory
+                    host = mine.cpu()
+                    bufs = [torch.empty_like(host) for _ in range(world)] if root else None
+                    dist.gather(host, bufs, dst=0)
+                    if root:
+                        gathered[g][: world * count * part_floats].copy_(torch.cat(bufs))
+                else:
+                    if untiled[g] is not None:
+                        joiner.wait_event(untiled[g])
+                    into = [gathered[g][r * count * part_floats:(r + 1) * count * part_floats] for r in range(world)] if root else None
+                    dist.gather(mine, into, dst=0)  # returns once enqueued; this stream then waits for RCCL's
+                sent[g] = joiner.record_event()
+            if root:
+                with torch.cuda.stream(side):
+                    side.wait_event(sent[g])
+                    # gathered[g] holds [rank][frame][block]: frame f starts at f blocks, the ranks lie count blocks apart
+                    for f in range(count):
+                        dev.untile_device(rargs, gathered[g].data_ptr() + f * part_floats * 4, fb.data_ptr(),
+                                          stream=side.cuda_stream, part_pitch_floats=count * part_floats)
+                    untiled[g] = side.record_event()
 
         def step(want_stats):
-            b = counter[0] % FLIGHTS
+            k = counter[0]
             counter[0] += 1
+            g, f, b = (k // GROUP) % 2, k % GROUP, k % FLIGHTS
             with torch.cuda.stream(streams[b]):
-                if pending[b] is not None:
-                    pending[b].wait()  # stream-level: the gather of FLIGHTS frames ago has released part[b]
-                if untiled[b] is not None:
-                    streams[b].wait_event(untiled[b])
-                st = devs[b].render_device(rargs, part[b].data_ptr(), stream=streams[b].cuda_stream, want_stats=want_stats)
-                if staged:
-                    host = part[b].cpu()
-                    bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                    dist.gather(host, bufs, dst=0)
-                    if rank == 0:
-                        gathered[b].copy_(torch.cat(bufs))
-                        devs[b].untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=streams[b].cuda_stream)
-                        torch.cuda.current_stream().synchronize()  # the next flight's un-tile writes the same frame
-                    return st
-                pending[b] = dist.gather(part[b], list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
-                                         async_op=True)
-            if rank == 0:
-                with torch.cuda.stream(side):
-                    pending[b].wait()
-                    devs[b].untile_device(rargs, gathered[b].data_ptr(), fb.data_ptr(), stream=side.cuda_stream)
-                    untiled[b] = side.record_event()
+                if sent[g] is not None:
+                    streams[b].wait_event(sent[g])  # the gather of two groups ago has released part[g]
+                st = devs[b].render_device(rargs, part[g].data_ptr() + f * part_floats * 4, stream=streams[b].cuda_stream,
+                                           want_stats=want_stats)
+            if f == GROUP - 1:
+                flush(g, GROUP)
             return st
 
         def drain():
-            for w in pending:
-                if w is not None:
-                    w.wait()
+            k = counter[0]
+            if k % GROUP:
+                flush((k // GROUP) % 2, k % GROUP)
+                counter[0] = (k // GROUP + 1) * GROUP  # the next frame starts a group
+            torch.cuda.current_stream().wait_stream(joiner)
             torch.cuda.current_stream().wait_stream(side)
 
     def fence():

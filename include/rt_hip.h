@@ -236,6 +236,15 @@ int rt_partition_tiles(uint32_t width, uint32_t height, const RtRenderArgs *args
 int rt_untile_device(RtBackend *backend, uint32_t width, uint32_t height, const RtRenderArgs *args,
                      const float *gathered_dev, float *fb_rgb_dev, void *hip_stream);
 
+/* The same with the parts' blocks `part_pitch_floats` apart instead of end to end (the pitch
+ * must be at least tiles_owned_max*tile_w*tile_h*3).  For a gather that brings several frames
+ * at once: each rank sends its blocks of F frames as one buffer, rank 0 receives
+ * [rank][frame][block], and frame f is un-tiled from gathered_dev + f*block with pitch
+ * F*block.  No counterpart in the reference (its render writes the framebuffer directly). */
+int rt_untile_device_pitched(RtBackend *backend, uint32_t width, uint32_t height, const RtRenderArgs *args,
+                             const float *gathered_dev, size_t part_pitch_floats, float *fb_rgb_dev,
+                             void *hip_stream);
+
 /* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
  * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).
  * origins/directions: n x 3 doubles (host).  Outputs (host): t (f32, unchanged

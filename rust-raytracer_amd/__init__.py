@@ -262,6 +262,7 @@ def lib() -> C.CDLL:
     L.rt_partition_tiles.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, C.c_uint32,
                                      C.POINTER(C.c_uint32)]
     L.rt_untile_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, vp, vp]
+    L.rt_untile_device_pitched.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), vp, C.c_size_t, vp, vp]
     L.rt_framebuffer_to_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.rt_save_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.rt_scene_point_light_count.argtypes = [vp]
@@ -510,9 +511,15 @@ class DeviceScene:
         )
         return stats
 
-    def untile_device(self, args: RtRenderArgs, gathered_dev_ptr: int, fb_dev_ptr: int, stream: int = 0) -> None:
-        _check(lib().rt_untile_device(self.backend.handle, self.width, self.height, C.byref(args), gathered_dev_ptr,
-                                      fb_dev_ptr, stream or None))
+    def untile_device(self, args: RtRenderArgs, gathered_dev_ptr: int, fb_dev_ptr: int, stream: int = 0,
+                      part_pitch_floats: int = 0) -> None:
+        """rt_untile_device; with `part_pitch_floats` the parts' blocks lie that far apart (rt_untile_device_pitched)."""
+        if part_pitch_floats:
+            _check(lib().rt_untile_device_pitched(self.backend.handle, self.width, self.height, C.byref(args),
+                                                  gathered_dev_ptr, part_pitch_floats, fb_dev_ptr, stream or None))
+        else:
+            _check(lib().rt_untile_device(self.backend.handle, self.width, self.height, C.byref(args), gathered_dev_ptr,
+                                          fb_dev_ptr, stream or None))
 
     def trace_rays(self, origins, directions, tmin, tmax, mode=RT_MODE_FAST):
         """BVH::closest_hit (geometry/bvh.rs:140) on caller-supplied rays."""

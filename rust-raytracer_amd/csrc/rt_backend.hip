@@ -337,15 +337,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_fill_i32(int32_t *p, size_t n, int
 }
 
 // Scatters gathered tile-major part buffers back into the i + j*width layout.
-// tile_where[k] = owner part * stride_tiles + slot of tile k inside that part.
-__global__ void __launch_bounds__(RT_BLOCK)
-k_untile(const float *gathered, float *fb, const uint32_t *tile_where, uint32_t width, uint32_t height, uint32_t tw,
-         uint32_t th, uint32_t tiles_x) {
+// tile_where[k] = (owner part << 20) | slot of tile k inside that part; a part's block of tiles
+// starts at part * pitch floats.  One-wave blocks: this kernel runs beside the packet kernels of
+// other frames, whose one-wave blocks take every wave slot as it frees; a 256-thread block needs a
+// free slot on all four SIMDs of one compute unit at the same moment and waits far longer for it.
+#define RT_UNTILE_BLOCK 64
+__global__ void __launch_bounds__(RT_UNTILE_BLOCK)
+k_untile(const float *gathered, size_t pitch, float *fb, const uint32_t *tile_where, uint32_t width, uint32_t height,
+         uint32_t tw, uint32_t th, uint32_t tiles_x) {
     const uint32_t n_px = width * height;
-    for (uint32_t px = blockIdx.x * RT_BLOCK + threadIdx.x; px < n_px; px += gridDim.x * RT_BLOCK) {
+    for (uint32_t px = blockIdx.x * RT_UNTILE_BLOCK + threadIdx.x; px < n_px; px += gridDim.x * RT_UNTILE_BLOCK) {
         const uint32_t i = px % width, j = px / width;
         const uint32_t tile = (j / th) * tiles_x + i / tw;
-        const size_t src = ((size_t)tile_where[tile] * tw * th + (size_t)(j % th) * tw + i % tw) * 3;
+        const uint32_t where = tile_where[tile];
+        const size_t src = (size_t)(where >> 20) * pitch + ((size_t)(where & 0xfffffu) * tw * th + (size_t)(j % th) * tw + i % tw) * 3;
         fb[(size_t)px * 3 + 0] = gathered[src + 0];
         fb[(size_t)px * 3 + 1] = gathered[src + 1];
         fb[(size_t)px * 3 + 2] = gathered[src + 2];
@@ -524,6 +529,15 @@ void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t par
 typedef RtEventPair EventPair;
 
 struct Timing {
+    Timing() = default;
+    Timing(const Timing &) = delete;
+    Timing &operator=(const Timing &) = delete;
+    ~Timing() {  // pairs that were neither collected nor handed to the backend (an error return)
+        for (auto &p : pairs) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+    }
     bool on = false;
     uint32_t mask = ~0u;  // kernel classes to time
     bool open = false;
@@ -534,7 +548,11 @@ struct Timing {
         if (!open) return 0;
         EventPair p;
         p.klass = klass;
-        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+        if (hipEventCreate(&p.a) != hipSuccess) return -1;
+        if (hipEventCreate(&p.b) != hipSuccess) {
+            (void)hipEventDestroy(p.a);
+            return -1;
+        }
         (void)hipEventRecord(p.a, stream);
         pairs.push_back(p);
         return 0;
@@ -623,7 +641,14 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     tm.on = stats != nullptr || args->timed_classes != 0;
     if (!stats) tm.mask = args->timed_classes;
     tm.stream = stream;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct FrameEvents {  // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~FrameEvents() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } frame_ev;
+    hipEvent_t &ev0 = frame_ev.a, &ev1 = frame_ev.b;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         RT_HIP(hipEventCreate(&ev0));
@@ -755,8 +780,6 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         float ms = 0.0f;
         RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         stats->render_ms = ms;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
         tm.collect(stats);
         bool overflow = false;
         // camera rays = samples of the owned pixels that lie inside the image
@@ -1066,6 +1089,12 @@ extern "C" int rt_partition_tiles(uint32_t width, uint32_t height, const RtRende
 
 extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, const RtRenderArgs *args,
                                 const float *gathered_dev, float *fb_rgb_dev, void *hip_stream) {
+    return rt_untile_device_pitched(be, width, height, args, gathered_dev, 0, fb_rgb_dev, hip_stream);
+}
+
+extern "C" int rt_untile_device_pitched(RtBackend *be, uint32_t width, uint32_t height, const RtRenderArgs *args,
+                                        const float *gathered_dev, size_t part_pitch_floats, float *fb_rgb_dev,
+                                        void *hip_stream) {
     if (!be || !args || !gathered_dev || !fb_rgb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
@@ -1073,6 +1102,10 @@ extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, 
     uint32_t stride = 0;
     int rc = rt_partition_info(width, height, args, nullptr, nullptr, &stride);
     if (rc) return rc;
+    const size_t block_floats = (size_t)stride * tw * th * 3;
+    if (part_pitch_floats == 0) part_pitch_floats = block_floats;  // end to end
+    if (part_pitch_floats < block_floats) return rt::set_error(RT_ERR_INVALID, "part pitch smaller than a part's block of tiles");
+    if (parts > 4096 || stride >= (1u << 20)) return rt::set_error(RT_ERR_INVALID, "too many parts or tiles per part for the un-tile table");
     RT_HIP(hipSetDevice(be->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : be->stream;
     const uint32_t key[5] = {width, height, tw, th, parts};
@@ -1082,7 +1115,7 @@ extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, 
         for (uint32_t ty = 0; ty < tiles_y; ++ty)
             for (uint32_t tx = 0; tx < tiles_x; ++tx) {
                 const uint32_t k = ty * tiles_x + tx, p = rt_tile_owner(tx, ty, parts, skew);
-                where[k] = p * stride + next[p]++;
+                where[k] = (p << 20) | next[p]++;
             }
         if (be->tile_where) (void)hipFree(be->tile_where);
         be->tile_where = nullptr;
@@ -1090,8 +1123,9 @@ extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, 
         RT_HIP(hipMemcpy(be->tile_where, where.data(), where.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         std::memcpy(be->untile_key, key, sizeof(key));
     }
-    hipLaunchKernelGGL(k_untile, dim3(grid_for((uint64_t)width * height)), dim3(RT_BLOCK), 0, stream, gathered_dev,
-                       fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x);
+    const uint64_t untile_blocks = ((uint64_t)width * height + RT_UNTILE_BLOCK - 1) / RT_UNTILE_BLOCK;
+    hipLaunchKernelGGL(k_untile, dim3((uint32_t)std::min<uint64_t>(untile_blocks, 4u * RT_MAX_GRID)), dim3(RT_UNTILE_BLOCK), 0, stream,
+                       gathered_dev, part_pitch_floats, fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -180,6 +180,34 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
     dev.close()
 
 
+def test_untile_of_frames_gathered_together(rt, backend, scene_path):
+    """A gather that brings several frames at once leaves rank 0 with [rank][frame][block]:
+    rt_untile_device_pitched restores frame f from offset f blocks with the ranks' blocks F blocks apart."""
+    import torch
+
+    W, H, tile, parts, frames = 250, 170, 16, 3, 2
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    whole = [dev.render(2, antialias_method=f, seed=7)[0].pixels for f in range(frames)]  # frame 0: regular grid, frame 1: jittered
+    a = dev.render_args(2, tile=(tile, tile), part=(0, parts))
+    _, _, stride = dev.partition_info(a)
+    block = stride * tile * tile * 3
+    gathered = torch.zeros(parts * frames * block, dtype=torch.float32, device="cuda")
+    fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(parts):
+        for f in range(frames):
+            a = dev.render_args(2, antialias_method=f, tile=(tile, tile), part=(p, parts), seed=7)
+            dev.render_device(a, gathered.data_ptr() + (p * frames + f) * block * 4, want_stats=True)
+    for f in range(frames):
+        dev.untile_device(a, gathered.data_ptr() + f * block * 4, fb.data_ptr(), part_pitch_floats=frames * block)
+        torch.cuda.synchronize()
+        assert np.array_equal(fb.cpu().numpy().reshape(H, W, 3), whole[f])
+    with pytest.raises(rt.RtError):  # a pitch smaller than a part's block
+        dev.untile_device(a, gathered.data_ptr(), fb.data_ptr(), part_pitch_floats=block - 3)
+    dev.close()
+
+
 @pytest.mark.parametrize("n,tile", [(1, 40), (2, 32), (4, 40), (5, 30), (8, 16), (3, 33), (2, 7), (1, 12)])
 def test_pixel_order_inside_tiles(rt, backend, scene_path, n, tile):
     """Inside a tile the pixels are worked in blocks sized to the samples per pixel (8x8 pixels at one
