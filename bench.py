@@ -163,7 +163,14 @@ def main():
     upload_s = (time.perf_counter() - t_up) / FLIGHTS
     dev = devs[0]
     mode = rt.RT_MODE_FAST if args.mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
-    rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world))
+    # Rank 0 also receives the other ranks' tiles and restores the image layout of every frame: with
+    # 1/8 frames that is a tenth of its time even when the gather is a local copy
+    # (tools/gather_host_cost.py: 0.184 ms per frame against 0.169 for the render alone), so from five
+    # GPUs on it takes 6/8 of the share the others get: its whole step then measures 0.152 ms, which
+    # leaves room for what a real seven-peer receive adds, and the other parts 0.164-0.180 ms
+    # (equal shares: 0.165-0.179).
+    part0_weight = int(os.environ.get("RT_BENCH_PART0_WEIGHT", "6" if many_parts else "0"))
+    rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight)
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
     tile_floats = tile * tile * 3
 
@@ -357,7 +364,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "traversal": args.mode, "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
-                       "frames_in_flight": FLIGHTS, "hw_queues": int(hw_queues) if hw_queues else "runtime default",
+                       "part0_weight": part0_weight, "frames_in_flight": FLIGHTS, "hw_queues": int(hw_queues) if hw_queues else "runtime default",
                        "scene_upload_ms": upload_s * 1e3,
                        "kernel_split_from": "warm-up frames (fully instrumented); roofline duration from the timed frames"},
             "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / n_stat for k in range(len(rt.KERNEL_CLASSES))},

@@ -135,10 +135,15 @@ typedef struct RtRenderArgs {
      * image in both directions (8 parts: skew 3, nearest tiles of a part 2.8
      * tiles apart).  rt_partition_tiles lists a part's tiles (row-major tile
      * numbers, ascending); rt_partition_info gives the counts.
-     * part_count <= 1 renders everything. */
+     * part_count <= 1 renders everything.
+     * part0_weight = w in 1..7 gives part 0 -- the device that also receives the other parts'
+     * tiles and restores the image layout -- a share w/8 of what each other part gets: the
+     * lattice then deals the tiles to w + 8 * (part_count - 1) lanes, of which part 0 owns w,
+     * evenly spaced, and every other part eight.  0 or 8: equal shares.  All parts of a frame,
+     * and rt_untile_device, must be given the same value. */
     uint32_t tile_w, tile_h;      /* 0 -> 32 */
     uint32_t part_index, part_count;
-    uint32_t reserved0;           /* 0 */
+    uint32_t part0_weight;        /* 0 */
     uint64_t seed;                /* key of the sample-offset generator (JITTERED / RANDOM) */
     /* render.rs:11, 80-82: the reference calls per_pixel_cb once for every finished pixel, on the
      * calling thread (the CLI advances a progress bar with it, main.rs:86-100).  A frame here

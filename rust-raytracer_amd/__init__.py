@@ -167,7 +167,7 @@ class RtRenderArgs(C.Structure):
         ("tile_h", C.c_uint32),
         ("part_index", C.c_uint32),
         ("part_count", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("part0_weight", C.c_uint32),
         ("seed", C.c_uint64),
         ("progress", C.c_void_p),
         ("progress_user", C.c_void_p),
@@ -461,22 +461,23 @@ class DeviceScene:
             pass
 
     def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-                    tile=(0, 0), part=(0, 1), seed=0) -> RtRenderArgs:
+                    tile=(0, 0), part=(0, 1), seed=0, part0_weight=0) -> RtRenderArgs:
         a = RtRenderArgs()
         a.sqrt_rays_per_pixel = int(sqrt_rays_per_pixel)
         a.antialias_method = int(antialias_method)
         a.mode = int(mode)
         a.tile_w, a.tile_h = int(tile[0]), int(tile[1])
         a.part_index, a.part_count = int(part[0]), int(part[1])
+        a.part0_weight = int(part0_weight)
         a.seed = int(seed)
         return a
 
     def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None):
+               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None, part0_weight=0):
         """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats).
         `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57);
         `progress(pixels_done, pixels_total)` is called after every finished batch of tiles."""
-        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed)
+        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed, part0_weight)
         keep = None
         if progress is not None:
             keep = PROGRESS_FN(lambda done, total, _user: progress(int(done), int(total)))

@@ -517,13 +517,22 @@ uint32_t grid_for(uint64_t work) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, RT_MAX_GRID));
 }
 
-// Tiles owned by `part` of `parts` (rt_tile_owner), ascending.
-void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t parts, std::vector<int32_t> &out) {
+// Tiles owned by `part` of `parts` (rt_tile_map), ascending.
+void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t parts, uint32_t part0_weight,
+                 std::vector<int32_t> &out) {
     out.clear();
-    const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
+    const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, part0_weight);
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
         for (uint32_t tx = 0; tx < tiles_x; ++tx)
-            if (rt_tile_owner(tx, ty, parts, skew) == part) out.push_back((int32_t)(ty * tiles_x + tx));
+            if (rt_tile_map_owner(map, tx, ty) == part) out.push_back((int32_t)(ty * tiles_x + tx));
+}
+
+// Shared argument check of everything that splits a frame.
+int check_partition(const RtRenderArgs *args) {
+    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    if (args->part0_weight > 8) return rt::set_error(RT_ERR_INVALID, "part0_weight must be 0 (equal shares) or 1..8");
+    return RT_OK;
 }
 
 typedef RtEventPair EventPair;
@@ -586,7 +595,7 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     if (args->mode != RT_MODE_FAST && args->mode != RT_MODE_REFERENCE_ORDER)
         return rt::set_error(RT_ERR_INVALID, "unknown traversal mode");
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    if (int bad = check_partition(args)) return bad;
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
     const uint32_t W = ds->width, H = ds->height;
     const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
@@ -603,9 +612,9 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     if (!stream) stream = be->stream;
 
     // ---- tile list (cached per partition)
-    const uint32_t key[6] = {W, H, tw, th, args->part_index, parts};
+    const uint32_t key[6] = {W, H, tw, th, args->part_index, parts | (args->part0_weight << 24)};
     if (std::memcmp(key, be->tile_key, sizeof(key)) != 0 || !be->tile_list) {
-        owned_tiles(tiles_x, tiles_y, args->part_index, parts, be->tile_list_host);
+        owned_tiles(tiles_x, tiles_y, args->part_index, parts, args->part0_weight, be->tile_list_host);
         if (be->tile_list) (void)hipFree(be->tile_list);
         be->tile_list = nullptr;
         RT_HIP(hipMalloc((void **)&be->tile_list, std::max<size_t>(be->tile_list_host.size(), 1) * sizeof(int32_t)));
@@ -1059,12 +1068,12 @@ extern "C" int rt_partition_info(uint32_t width, uint32_t height, const RtRender
     if (!args) return rt::set_error(RT_ERR_INVALID, "null argument");
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    if (int bad = check_partition(args)) return bad;
     const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
     std::vector<uint32_t> per_part(parts, 0);
-    const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
+    const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, args->part0_weight);
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
-        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_owner(tx, ty, parts, skew)]++;
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_map_owner(map, tx, ty)]++;
     if (tiles_total) *tiles_total = tiles_x * tiles_y;
     if (tiles_owned) *tiles_owned = per_part[args->part_index];
     if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());
@@ -1076,9 +1085,9 @@ extern "C" int rt_partition_tiles(uint32_t width, uint32_t height, const RtRende
     if (!args || !count_out) return rt::set_error(RT_ERR_INVALID, "null argument");
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    if (args->part_index >= parts) return rt::set_error(RT_ERR_INVALID, "part_index out of range");
+    if (int bad = check_partition(args)) return bad;
     std::vector<int32_t> tiles;
-    owned_tiles((width + tw - 1) / tw, (height + th - 1) / th, args->part_index, parts, tiles);
+    owned_tiles((width + tw - 1) / tw, (height + th - 1) / th, args->part_index, parts, args->part0_weight, tiles);
     *count_out = (uint32_t)tiles.size();
     if (tiles_out) {
         if (capacity < tiles.size()) return rt::set_error(RT_ERR_INVALID, "tile buffer too small");
@@ -1108,13 +1117,13 @@ extern "C" int rt_untile_device_pitched(RtBackend *be, uint32_t width, uint32_t 
     if (parts > 4096 || stride >= (1u << 20)) return rt::set_error(RT_ERR_INVALID, "too many parts or tiles per part for the un-tile table");
     RT_HIP(hipSetDevice(be->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : be->stream;
-    const uint32_t key[5] = {width, height, tw, th, parts};
+    const uint32_t key[5] = {width, height, tw, th, parts | (args->part0_weight << 24)};
     if (std::memcmp(key, be->untile_key, sizeof(key)) != 0 || !be->tile_where) {
         std::vector<uint32_t> where((size_t)tiles_x * tiles_y), next(parts, 0);
-        const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
+        const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, args->part0_weight);
         for (uint32_t ty = 0; ty < tiles_y; ++ty)
             for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-                const uint32_t k = ty * tiles_x + tx, p = rt_tile_owner(tx, ty, parts, skew);
+                const uint32_t k = ty * tiles_x + tx, p = rt_tile_map_owner(map, tx, ty);
                 where[k] = (p << 20) | next[p]++;
             }
         if (be->tile_where) (void)hipFree(be->tile_where);

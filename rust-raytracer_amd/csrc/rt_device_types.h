@@ -91,6 +91,36 @@ inline uint32_t rt_tile_skew(uint32_t tiles_x, uint32_t tiles_y, uint32_t parts)
     return best;
 }
 
+// The split of a frame over `parts` devices, optionally with a smaller share for part 0 (the device
+// that also receives the other parts' tiles and restores the image layout).  `part0_weight` = w in
+// 1..7 gives part 0 a share w/8 of what each other part gets: the tiles are dealt to w + 8 * (parts - 1)
+// LANES on the lattice above, part 0 owns w of them spaced evenly through the residues (so its tiles
+// stay spread over the image), and the remaining lanes go to parts 1, 2, ... in turn, eight each.
+// 0 or 8 = equal shares: one lane per part.
+struct RtTileMap {
+    uint32_t parts, lanes, skew;
+    uint32_t lead, step;  // part 0 owns lanes 0, step, 2 * step, ... (lead of them); lead = 0: lane = part
+};
+
+inline RtTileMap rt_tile_map(uint32_t tiles_x, uint32_t tiles_y, uint32_t parts, uint32_t part0_weight) {
+    RtTileMap m;
+    m.parts = parts < 1 ? 1 : parts;
+    m.lead = (m.parts >= 2 && part0_weight >= 1 && part0_weight <= 7) ? part0_weight : 0;
+    m.lanes = m.lead ? m.lead + 8u * (m.parts - 1u) : m.parts;
+    m.step = m.lead ? m.lanes / m.lead : 1u;
+    m.skew = rt_tile_skew(tiles_x, tiles_y, m.lanes);
+    return m;
+}
+
+inline uint32_t rt_tile_map_owner(const RtTileMap &m, uint32_t tx, uint32_t ty) {
+    const uint32_t lane = rt_tile_owner(tx, ty, m.lanes, m.skew);
+    if (!m.lead) return lane;
+    const uint32_t q = lane / m.step;
+    if (lane % m.step == 0 && q < m.lead) return 0;
+    const uint32_t part0_lanes_below = q + 1 < m.lead ? q + 1 : m.lead;  // of lanes 0 .. lane
+    return 1u + (lane - part0_lanes_below) % (m.parts - 1u);
+}
+
 // Pixel block of the in-tile order (RtBatch::blk_*_log2): the power-of-two block, as square as
 // possible (wider than high if not), that holds about 64 samples and divides the tile.
 inline void rt_pixel_block(uint32_t tile_w, uint32_t tile_h, uint32_t samples_per_pixel, uint32_t &w_log2, uint32_t &h_log2) {

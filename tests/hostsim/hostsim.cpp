@@ -118,10 +118,10 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
     const uint32_t parts = std::max<uint32_t>(args.part_count, 1);
     std::vector<int32_t> tile_list;
-    const uint32_t skew = rt_tile_skew(tiles_x, tiles_y, parts);
+    const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, args.part0_weight);
     for (uint32_t ty = 0; ty < tiles_y; ++ty)
         for (uint32_t tx = 0; tx < tiles_x; ++tx)
-            if (rt_tile_owner(tx, ty, parts, skew) == args.part_index) tile_list.push_back((int32_t)(ty * tiles_x + tx));
+            if (rt_tile_map_owner(map, tx, ty) == args.part_index) tile_list.push_back((int32_t)(ty * tiles_x + tx));
     const uint32_t n_slots = (uint32_t)tile_list.size();
     const uint32_t cap = n_slots * tw * th * spp;
     const uint32_t npl = (uint32_t)S.n_point_lights;

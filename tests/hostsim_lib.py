@@ -37,13 +37,14 @@ def lib():
     return _lib
 
 
-def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), part=(0, 1), aa=0, seed=0):
+def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), part=(0, 1), aa=0, seed=0, part0_weight=0):
     W, H = scene.image_width, scene.image_height
     a = rt.RtRenderArgs()
     a.sqrt_rays_per_pixel = sqrt_rpp
     a.mode = mode
     a.tile_w, a.tile_h = tile
     a.part_index, a.part_count = part
+    a.part0_weight = part0_weight
     a.antialias_method, a.seed = int(aa), int(seed)
     fb = np.zeros((H, W, 3), np.float32)
     ids = rt.RayIds(W * H * sqrt_rpp * sqrt_rpp, scene.n_point_lights) if want_ids else None

@@ -101,6 +101,38 @@ def test_partition_is_balanced_and_interleaved(rt):
             assert d2.min() >= {2: 2, 3: 2, 4: 2, 8: 8}[parts], (width, tile, parts, d2.min())
 
 
+def test_partition_with_a_smaller_share_for_part_0(rt):
+    """part0_weight = w: part 0 gets w/8 of what each other part gets, the others stay equal among
+    themselves, every tile has exactly one owner, and part 0's tiles stay spread over the image."""
+    for width, tile, parts, w in ((1000, 40, 8, 7), (1000, 40, 8, 4), (1000, 40, 4, 7), (3840, 32, 8, 6), (1000, 40, 2, 5)):
+        tiles_x = (width + tile - 1) // tile
+        counts, everything = [], []
+        for p in range(parts):
+            a = rt.RtRenderArgs()
+            a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count, a.part0_weight = 3, tile, tile, p, parts, w
+            t = rt.partition_tiles(width, width, a)
+            counts.append(t.size)
+            everything.append(t)
+        assert sorted(np.concatenate(everything).tolist()) == list(range(tiles_x * tiles_x))
+        others = counts[1:]
+        assert max(others) - min(others) <= max(2, 0.02 * max(others)), (width, parts, w, counts)
+        ratio = counts[0] / (sum(others) / len(others))
+        assert abs(ratio - w / 8) < 0.03, (width, parts, w, counts)
+        # part 0 is present in (nearly) every tile row and never owns two neighbouring tiles of a row
+        rows = everything[0] // tiles_x
+        assert len(set(rows.tolist())) >= tiles_x - 2
+        same_row = np.diff(everything[0])[np.diff(rows) == 0]
+        assert same_row.size == 0 or same_row.min() >= 2
+    # weight 0 and weight 8 are the equal split
+    a, b = rt.RtRenderArgs(), rt.RtRenderArgs()
+    for x, w in ((a, 0), (b, 8)):
+        x.sqrt_rays_per_pixel, x.tile_w, x.tile_h, x.part_index, x.part_count, x.part0_weight = 3, 40, 40, 3, 8, w
+    assert np.array_equal(rt.partition_tiles(1000, 1000, a), rt.partition_tiles(1000, 1000, b))
+    a.part0_weight = 9
+    with pytest.raises(rt.RtError):
+        rt.partition_tiles(1000, 1000, a)
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
 def test_device_entry_points_fail_loudly_without_gpu(rt, scene_path):
     with pytest.raises(rt.RtError) as e:

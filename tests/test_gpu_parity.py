@@ -145,25 +145,28 @@ def test_batched_render_equals_single_batch(rt, backend, scene_path):
     dev.close()
 
 
-@pytest.mark.parametrize("parts", [2, 3, 8])
-def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, parts):
+@pytest.mark.parametrize("parts,weight", [(2, 0), (3, 0), (8, 0), (8, 7), (3, 4)])
+def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, parts, weight):
     """The multi-GPU protocol on one GPU: every part renders its tiles into a compact device buffer,
-    the buffers are laid end to end as a gather would, rt_untile_device restores the frame."""
+    the buffers are laid end to end as a gather would, rt_untile_device restores the frame.  With
+    `weight` part 0 takes a smaller share of the tiles (RtRenderArgs.part0_weight)."""
     import torch
 
     W, H, tile = 250, 170, 16
     scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
     dev = backend.upload(scene)
     full, _, full_stats = dev.render(2)
-    a = dev.render_args(2, tile=(tile, tile), part=(0, parts))
+    a = dev.render_args(2, tile=(tile, tile), part=(0, parts), part0_weight=weight)
     total, owned, stride = dev.partition_info(a)
+    if weight:
+        assert owned < stride  # part 0 holds fewer tiles than the largest part
     part_floats = stride * tile * tile * 3
     gathered = torch.zeros(parts * part_floats, dtype=torch.float32, device="cuda")
     fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()  # the fills ran on torch's stream, the renders use the backend's own
     rays = 0
     for p in range(parts):
-        a = dev.render_args(2, tile=(tile, tile), part=(p, parts))
+        a = dev.render_args(2, tile=(tile, tile), part=(p, parts), part0_weight=weight)
         st = dev.render_device(a, gathered.data_ptr() + p * part_floats * 4, want_stats=True)
         rays += st.total_rays()
     dev.untile_device(a, gathered.data_ptr(), fb.data_ptr())
@@ -174,7 +177,7 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
     # host-buffer variant: a part writes only its own tiles of the full-layout image
     merged = np.zeros_like(full.pixels)
     for p in range(parts):
-        fbp, _, _ = dev.render(2, tile=(tile, tile), part=(p, parts))
+        fbp, _, _ = dev.render(2, tile=(tile, tile), part=(p, parts), part0_weight=weight)
         merged += fbp.pixels
     assert np.array_equal(merged, full.pixels)
     dev.close()

@@ -98,10 +98,10 @@ def test_fast_mesh_trees_change_no_hit(rt, scene_path, monkeypatch):
     assert st_a.total_rays() == st_b.total_rays()
 
 
-@pytest.mark.parametrize("parts", [2, 3])
-def test_partitioned_render_tiles_the_image(rt, scene_path, parts):
+@pytest.mark.parametrize("parts,weight", [(2, 0), (3, 0), (3, 5)])
+def test_partitioned_render_tiles_the_image(rt, scene_path, parts, weight):
     """Each part renders only the tiles it owns; the parts are disjoint, cover the image, and their
-    pixels are bit-identical with the unpartitioned frame."""
+    pixels are bit-identical with the unpartitioned frame -- also when part 0 takes a smaller share."""
     sc = rt.parse_scene_file(scene_path("mixed_features"), image_width=100, image_height=70, recursion_depth=6)
     tile = (16, 16)
     full, _, _ = HS.render(sc, 2, want_ids=False, tile=tile)
@@ -110,10 +110,10 @@ def test_partitioned_render_tiles_the_image(rt, scene_path, parts):
     merged = np.zeros_like(full)
     for p in range(parts):
         a = rt.RtRenderArgs()
-        a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count = 2, 16, 16, p, parts
+        a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count, a.part0_weight = 2, 16, 16, p, parts, weight
         owned = rt.partition_tiles(100, 70, a)  # the shipped library's ownership rule
         seen[owned] += 1
-        fb, _, _ = HS.render(sc, 2, want_ids=False, tile=tile, part=(p, parts))
+        fb, _, _ = HS.render(sc, 2, want_ids=False, tile=tile, part=(p, parts), part0_weight=weight)
         mask = np.zeros((70, 100), bool)
         for k in owned:
             ty, tx = divmod(int(k), tiles_x)

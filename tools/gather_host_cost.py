@@ -7,7 +7,8 @@ torch.distributed layers alone -- a lower bound of what a real 8-rank gather add
     python3 tools/gather_host_cost.py [frames] [group]
 
 group = frames gathered together (1 = a gather per frame; bench.py gathers the frames in flight together).
-RT_FLIGHTS = frames in flight (default 8), GPU_MAX_HW_QUEUES as for bench.py.
+RT_FLIGHTS = frames in flight (default 8), RT_PARTS = parts (default 8), RT_PART0_WEIGHT = RtRenderArgs.part0_weight
+(default 0), GPU_MAX_HW_QUEUES as for bench.py.
 """
 import importlib
 import os
@@ -38,7 +39,7 @@ def main():
                                 recursion_depth=depth)
     bes = [rt.Backend(0) for _ in range(flights)]
     devs = [b.upload(scene) for b in bes]
-    a = devs[0].render_args(n, tile=(tile, tile), part=(0, parts))
+    a = devs[0].render_args(n, tile=(tile, tile), part=(0, parts), part0_weight=int(os.environ.get("RT_PART0_WEIGHT", "0")))
     _, owned, stride = devs[0].partition_info(a)
     pf = stride * tile * tile * 3
     streams = [torch.cuda.Stream() for _ in range(flights)]

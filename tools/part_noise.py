@@ -33,7 +33,7 @@ def main():
     bufs = [torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") for _ in range(flights)]
     out = []
     for p in order:
-        a = devs[0].render_args(n, tile=(tile, tile), part=(p, parts))
+        a = devs[0].render_args(n, tile=(tile, tile), part=(p, parts), part0_weight=int(os.environ.get("RT_PART0_WEIGHT", "0")))
         for k in range(3 * flights):
             devs[k % flights].render_device(a, bufs[k % flights].data_ptr(), stream=sts[k % flights].cuda_stream)
         torch.cuda.synchronize()
