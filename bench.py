@@ -127,6 +127,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RT_BENCH_MULTI_PATH=1 runs the N > 1 code (process group, grouped gather, un-tile) with a single
+    # rank, as a check of that path on a one-GPU machine; the figures are then not the N = 1 benchmark.
+    multi = world > 1 or os.environ.get("RT_BENCH_MULTI_PATH", "0") == "1"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -134,7 +137,7 @@ def main():
     if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":  # rehearsal of the N > 1 path on a single GPU
             dist.init_process_group("gloo")
         else:
@@ -144,7 +147,7 @@ def main():
     gen = importlib.import_module("scenes.gen_scenes")
     if rank == 0:
         gen.ensure_models()
-    if world > 1:
+    if multi:
         dist.barrier()
 
     scene_name, W, H, n, depth, tile, desc = WORKLOADS[args.workload]
@@ -178,10 +181,10 @@ def main():
     # stream", which would not be ordered with torch's copies and collectives.
     streams = [torch.cuda.Stream() for _ in range(FLIGHTS)]
     torch.cuda.set_stream(streams[0])
-    staged = world > 1 and dist.get_backend() != "nccl"  # rehearsal on one GPU: gather through host memory (gloo)
+    staged = multi and dist.get_backend() != "nccl"  # rehearsal on one GPU: gather through host memory (gloo)
     counter = [0]
 
-    if world == 1:
+    if not multi:
         fbs = [torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") for _ in range(FLIGHTS)]
         fb = fbs[0]
 
@@ -261,7 +264,7 @@ def main():
 
     def fence():
         drain()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -296,7 +299,9 @@ def main():
     # Outside the timed region: the gathered frame must be bit-identical with the same frame rendered
     # whole on rank 0 (static tile map, ordered per-pixel sums).
     frame_check = None
-    if world > 1 and rank == 0:
+    if multi and world == 1:
+        frame_check = "not applicable: a single part is rendered in image layout, not tile by tile"
+    elif multi and rank == 0:
         whole = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
         dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile)), whole.data_ptr(), stream=streams[0].cuda_stream)
         torch.cuda.synchronize()
@@ -306,7 +311,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -336,7 +341,7 @@ def main():
             bytes_per_launch = bytes_per_step / launches_per_step
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, dom_name) if world == 1 else None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, dom_name) if not multi else None,
                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                         "launches_timed": int(timed.kernel_launches[dom])}
             # In the timed region the kernels of FLIGHTS frames share the GPU, so one launch lasts
@@ -344,7 +349,7 @@ def main():
             alone_ms = k_ms[dom] / max(k_n[dom], 1)
             alone = bytes_per_launch / (alone_ms * 1e-3) / 1e9
             roofline["alone_on_the_gpu"] = {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS}
-            if world == 1:
+            if not multi:
                 torch.cuda.set_stream(torch.cuda.default_stream())
                 hbm = measured_hbm_gbs(torch)
                 roofline["peak_measured"] = hbm  # copy / triad on this box, GB/s
@@ -373,7 +378,7 @@ def main():
         }
         if frame_check:
             out["config"]["frame_check"] = frame_check
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             # one frame of the benchmarked workload itself on one core (the reference's loop is serial,
             # render.rs:36-50): about 9 s for the bunny frame; the 4K workload is sampled at 1000x1000
             sample_px = 1000
@@ -391,7 +396,7 @@ def main():
         d.close()
     for be in backends:
         be.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
