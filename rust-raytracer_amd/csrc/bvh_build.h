@@ -33,8 +33,10 @@ struct Tree {
 Tree build_tree(std::vector<BuildItem> items);
 
 // Binned surface-area-heuristic tree with at most `max_leaf` items per leaf (not the reference's
-// tree: only for traversal that does not depend on the reference's visiting order).
-Tree build_tree_sah(std::vector<BuildItem> items, size_t max_leaf);
+// tree: only for traversal that does not depend on the reference's visiting order).  `node_cost` =
+// cost of a node step in units of one item test: a group of <= max_leaf items stays a leaf unless
+// splitting it saves more than that.
+Tree build_tree_sah(std::vector<BuildItem> items, size_t max_leaf, double node_cost);
 
 struct FlatScene {
     std::vector<RtNode> nodes;
