@@ -367,7 +367,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc, "traversal": args.mode, "tile": tile, "tiles": tiles_total,
+            "config": {"workload": desc, "traversal": args.mode,
+                       "precision": "fp32 tree search, f64 hit refinement and shading, f32 colour (as the reference's f64 geometry / f32 colour)",
+                       "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
                        "part0_weight": part0_weight, "frames_in_flight": FLIGHTS, "hw_queues": int(hw_queues) if hw_queues else "runtime default",
                        "scene_upload_ms": upload_s * 1e3,
