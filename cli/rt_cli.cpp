@@ -4,7 +4,7 @@
 //
 //   rt-cli -i scene.json [-o out.png] [-x W] [-y H] [-r RPP] [-d DEPTH] [--aspect-ratio A]
 //          [--disable-shadows] [--render-normals] [--antialias-method normal|jittered|random] [--seed N]
-//          [--backend hip] [--device N] [--mode fast|reference] [--stats-json FILE]
+//          [--backend hip] [--device N] [--mode fast|reference] [--stats-json FILE] [--dump-ids FILE]
 //
 // Only the HIP backend exists in this program; there is no CPU renderer to fall back to.
 #include <cmath>
@@ -48,7 +48,8 @@ void usage() {
                  "      --backend <hip>                 [default: hip]\n"
                  "      --device <ORDINAL>              [default: 0]\n"
                  "      --mode <fast|reference>         traversal order [default: fast]\n"
-                 "      --stats-json <FILE>             ray counts and kernel times of the frame\n");
+                 "      --stats-json <FILE>             ray counts and kernel times of the frame\n"
+                 "      --dump-ids <FILE>               per-sample hit ids of the frame (binary, see rt_cli.cpp)\n");
 }
 
 }  // namespace
@@ -57,7 +58,7 @@ int main(int argc, char **argv) {
     RtParseArgs pa;
     std::memset(&pa, 0, sizeof(pa));
     pa.recursion_depth = -1;
-    std::string scene_path, output = "out.png", stats_json, backend = "hip";
+    std::string scene_path, output = "out.png", stats_json, dump_ids, backend = "hip";
     long rays_per_pixel = 4;  // DEFAULT_RAYS_PER_PIXEL, prelude.rs:56
     int aa = RT_AA_NORMAL, mode = RT_MODE_FAST, device = 0;
     bool have_seed = false;
@@ -98,6 +99,7 @@ int main(int argc, char **argv) {
             else if (v == "reference") mode = RT_MODE_REFERENCE_ORDER;
             else return fail("invalid value '" + v + "' for '--mode'");
         } else if (a == "--stats-json") stats_json = value("--stats-json");
+        else if (a == "--dump-ids") dump_ids = value("--dump-ids");
         else if (a == "-h" || a == "--help") {
             usage();
             return 0;
@@ -151,7 +153,27 @@ int main(int argc, char **argv) {
             std::fprintf(stderr, "\rRendering: %3.0f %%", total ? 100.0 * (double)done / (double)total : 100.0);
             if (done == total) std::fprintf(stderr, "\n");
         };
-    rc = rt_render(be, ds, &ra, fb.data(), nullptr, &st);
+    // --dump-ids: the RtRayIds arrays of the frame, for comparing hits with another renderer.  File:
+    // "RTID", then u32 version (1), width, height, samples per pixel, point lights, then seven int32
+    // arrays: primary_shape, primary_tri, final_shape, final_tri, bounces (one entry per sample, sample
+    // index = (i + j * width) * spp + p * n + q), shadow_shape, shadow_tri (point lights entries per sample).
+    const size_t samples = (size_t)W * H * (size_t)(n * n);
+    const size_t npl = rt_scene_point_light_count(ds);
+    std::vector<int32_t> id_store;
+    RtRayIds ids;
+    std::memset(&ids, 0, sizeof(ids));
+    if (!dump_ids.empty()) {
+        id_store.assign(samples * (5 + 2 * npl), -1);
+        int32_t *at = id_store.data();
+        ids.primary_shape = at; at += samples;
+        ids.primary_tri = at; at += samples;
+        ids.final_shape = at; at += samples;
+        ids.final_tri = at; at += samples;
+        ids.bounces = at; at += samples;
+        ids.shadow_shape = at; at += samples * npl;
+        ids.shadow_tri = at;
+    }
+    rc = rt_render(be, ds, &ra, fb.data(), dump_ids.empty() ? nullptr : &ids, &st);
     int exit_code = 0;
     if (rc != RT_OK) {
         exit_code = fail_rt("render");
@@ -161,6 +183,14 @@ int main(int argc, char **argv) {
         const double rays = (double)(st.primary_rays + st.secondary_rays + st.shadow_rays);
         std::fprintf(stderr, "Render complete: %ux%u, %ld rays per pixel, %.0f rays in %.3f ms (%.2f Grays/s)\n", W, H,
                      rays_per_pixel, rays, st.render_ms, rays / (st.render_ms * 1e6));
+        if (!dump_ids.empty()) {
+            FILE *f = std::fopen(dump_ids.c_str(), "wb");
+            const uint32_t head[5] = {1u, W, H, (uint32_t)(n * n), (uint32_t)npl};
+            if (!f || std::fwrite("RTID", 1, 4, f) != 4 || std::fwrite(head, sizeof(head), 1, f) != 1 ||
+                std::fwrite(id_store.data(), sizeof(int32_t), id_store.size(), f) != id_store.size())
+                exit_code = fail("cannot write " + dump_ids);
+            if (f) std::fclose(f);
+        }
         if (!stats_json.empty()) {
             FILE *f = std::fopen(stats_json.c_str(), "w");
             if (!f) {

@@ -62,13 +62,24 @@ def test_cli_renders_what_the_library_renders(cli, rt, backend, scene_path, tmp_
 
     out = str(tmp_path / "frame.png")
     stats = str(tmp_path / "stats.json")
+    ids_path = str(tmp_path / "ids.bin")
     rc, err = run(cli, "-i", scene_path("mixed_features"), "-o", out, "-x", "120", "-y", "80", "-r", "9", "-d", "4",
-                  "--stats-json", stats)
+                  "--stats-json", stats, "--dump-ids", ids_path)
     assert rc == 0, err
     scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=120, image_height=80, recursion_depth=4)
     dev = backend.upload(scene)
-    fb, _, st = dev.render(3)
+    fb, ids, st = dev.render(3, want_ids=True)
     assert np.array_equal(np.asarray(Image.open(out).convert("RGB")), fb.to_rgb8())
+    raw = open(ids_path, "rb").read()
+    assert raw[:4] == b"RTID"
+    version, w, h, spp, npl = np.frombuffer(raw, np.uint32, 5, 4)
+    assert (version, w, h, spp, npl) == (1, 120, 80, 9, scene.n_point_lights)
+    body = np.frombuffer(raw, np.int32, offset=24)
+    samples = 120 * 80 * 9
+    assert body.size == samples * (5 + 2 * npl)
+    assert np.array_equal(body[:samples], ids.primary_shape) and np.array_equal(body[samples:2 * samples], ids.primary_tri)
+    assert np.array_equal(body[2 * samples:3 * samples], ids.final_shape) and np.array_equal(body[4 * samples:5 * samples], ids.bounces)
+    assert np.array_equal(body[5 * samples:5 * samples + samples * npl] >= 0, np.asarray(ids.shadow_shape).reshape(-1) >= 0)
     s = json.load(open(stats))
     assert s["primary_rays"] == st.primary_rays == 120 * 80 * 9
     assert s["shadow_rays"] == st.shadow_rays and s["secondary_rays"] == st.secondary_rays
