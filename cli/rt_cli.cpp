@@ -4,7 +4,8 @@
 //
 //   rt-cli -i scene.json [-o out.png] [-x W] [-y H] [-r RPP] [-d DEPTH] [--aspect-ratio A]
 //          [--disable-shadows] [--render-normals] [--antialias-method normal|jittered|random] [--seed N]
-//          [--backend hip] [--device N] [--mode fast|reference] [--stats-json FILE] [--dump-ids FILE]
+//          [--backend hip] [--device N] [--gpus N [--same-device]] [--mode fast|reference]
+//          [--stats-json FILE] [--dump-ids FILE]
 //
 // Only the HIP backend exists in this program; there is no CPU renderer to fall back to.
 #include <cmath>
@@ -49,6 +50,8 @@ void usage() {
                  "      --device <ORDINAL>              [default: 0]\n"
                  "      --mode <fast|reference>         traversal order [default: fast]\n"
                  "      --stats-json <FILE>             ray counts and kernel times of the frame\n"
+                 "      --gpus <N>                      split the frame over devices --device .. --device + N - 1 [default: 1]\n"
+                 "      --same-device                   with --gpus: all parts on --device (checks the split on a one-GPU machine)\n"
                  "      --dump-ids <FILE>               per-sample hit ids of the frame (binary, see rt_cli.cpp)\n");
 }
 
@@ -61,6 +64,8 @@ int main(int argc, char **argv) {
     std::string scene_path, output = "out.png", stats_json, dump_ids, backend = "hip";
     long rays_per_pixel = 4;  // DEFAULT_RAYS_PER_PIXEL, prelude.rs:56
     int aa = RT_AA_NORMAL, mode = RT_MODE_FAST, device = 0;
+    long gpus = 1;
+    bool same_device = false;
     bool have_seed = false;
     uint64_t seed = 0;
 
@@ -93,6 +98,8 @@ int main(int argc, char **argv) {
             have_seed = true;
         } else if (a == "--backend") backend = value("--backend");
         else if (a == "--device") device = (int)std::strtol(value("--device"), nullptr, 10);
+        else if (a == "--gpus") gpus = std::strtol(value("--gpus"), nullptr, 10);
+        else if (a == "--same-device") same_device = true;
         else if (a == "--mode") {
             const std::string v = value("--mode");
             if (v == "fast") mode = RT_MODE_FAST;
@@ -113,6 +120,8 @@ int main(int argc, char **argv) {
         return fail("the following required arguments were not provided: --scene-path <SCENE_PATH>");
     }
     if (backend != "hip") return fail("backend '" + backend + "' is not part of this program (only 'hip' is)");
+    if (gpus < 1 || gpus > 64) return fail("invalid value for '--gpus'");
+    if (gpus > 1 && !dump_ids.empty()) return fail("'--dump-ids' cannot be used with '--gpus'");
 
     // main.rs:72-83: rays per pixel must be a perfect square
     if (rays_per_pixel <= 0 || rays_per_pixel > 65535) return fail("rays_per_pixel must be a perfect square");
@@ -132,6 +141,28 @@ int main(int argc, char **argv) {
         rt_backend_destroy(be);
         rt_scene_destroy(scene);
         return fail_rt("upload");
+    }
+    // --gpus N: one backend and one copy of the scene per further device (the first is `be` / `ds`)
+    std::vector<RtBackend *> all_be(1, be);
+    std::vector<RtDeviceScene *> all_ds(1, ds);
+    auto destroy_all = [&]() {
+        for (size_t k = all_ds.size(); k-- > 0;) rt_scene_free(all_ds[k]);
+        for (size_t k = all_be.size(); k-- > 0;) rt_backend_destroy(all_be[k]);
+        rt_scene_destroy(scene);
+    };
+    for (long k = 1; k < gpus; ++k) {
+        RtBackend *bk = nullptr;
+        RtDeviceScene *dk = nullptr;
+        if (rt_backend_create(same_device ? device : device + (int)k, &bk) != RT_OK) {
+            destroy_all();
+            return fail_rt("backend");
+        }
+        all_be.push_back(bk);
+        if (rt_scene_upload(bk, scene, &dk) != RT_OK) {
+            destroy_all();
+            return fail_rt("upload");
+        }
+        all_ds.push_back(dk);
     }
     RtRenderArgs ra;
     std::memset(&ra, 0, sizeof(ra));
@@ -173,7 +204,13 @@ int main(int argc, char **argv) {
         ids.shadow_shape = at; at += samples * npl;
         ids.shadow_tri = at;
     }
-    rc = rt_render(be, ds, &ra, fb.data(), dump_ids.empty() ? nullptr : &ids, &st);
+    if (gpus > 1) {
+        ra.tile_w = ra.tile_h = 32;
+        ra.part0_weight = gpus > 4 ? 7 : 0;  // the first device also collects the tiles
+        rc = rt_render_multi(all_be.data(), all_ds.data(), (uint32_t)gpus, &ra, fb.data(), &st);
+    } else {
+        rc = rt_render(be, ds, &ra, fb.data(), dump_ids.empty() ? nullptr : &ids, &st);
+    }
     int exit_code = 0;
     if (rc != RT_OK) {
         exit_code = fail_rt("render");
@@ -208,8 +245,6 @@ int main(int argc, char **argv) {
             }
         }
     }
-    rt_scene_free(ds);
-    rt_backend_destroy(be);
-    rt_scene_destroy(scene);
+    destroy_all();
     return exit_code;
 }

@@ -250,6 +250,17 @@ int rt_untile_device_pitched(RtBackend *backend, uint32_t width, uint32_t height
                              const float *gathered_dev, size_t part_pitch_floats, float *fb_rgb_dev,
                              void *hip_stream);
 
+/* render (render.rs:7-23) with the frame split over `n` backends in ONE process -- what a
+ * front end with a `--gpus N` flag calls.  backends[k] / dev_scenes[k] (the same scene, uploaded
+ * through backends[k]) render part k of n concurrently, one host thread each; the parts' tiles
+ * are then copied to backends[0]'s device (peer copies), un-tiled there and returned in host
+ * memory like rt_render's.  args->part_index / part_count are ignored (set per part),
+ * part0_weight is honoured, progress is not called.  The backends may sit on different devices
+ * or share one.  stats_out (may be NULL): ray counts and kernel times summed over the parts,
+ * render_ms = wall time of the whole call.  n = 1 is rt_render. */
+int rt_render_multi(RtBackend *const *backends, RtDeviceScene *const *dev_scenes, uint32_t n,
+                    const RtRenderArgs *args, float *fb_rgb, RtStats *stats_out);
+
 /* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
  * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).
  * origins/directions: n x 3 doubles (host).  Outputs (host): t (f32, unchanged

@@ -255,6 +255,7 @@ def lib() -> C.CDLL:
     L.rt_scene_free.restype = None
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), C.POINTER(RtStats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp, C.POINTER(RtStats)]
+    L.rt_render_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(RtRenderArgs), vp, C.POINTER(RtStats)]
     L.rt_collect_timings.argtypes = [vp, C.POINTER(RtStats)]
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
     L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
@@ -274,6 +275,18 @@ def lib() -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != RT_OK:
         raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
+
+
+def render_multi(dev_scenes, args: "RtRenderArgs"):
+    """rt_render_multi: one frame split over the given DeviceScenes (one backend each).  Returns (pixels, RtStats)."""
+    n = len(dev_scenes)
+    bes = (C.c_void_p * n)(*[d.backend.handle for d in dev_scenes])
+    dss = (C.c_void_p * n)(*[d._h for d in dev_scenes])
+    W, H = dev_scenes[0].width, dev_scenes[0].height
+    fb = np.zeros((H, W, 3), np.float32)
+    stats = RtStats()
+    _check(lib().rt_render_multi(bes, dss, n, C.byref(args), fb.ctypes.data, C.byref(stats)))
+    return fb, stats
 
 
 def partition_tiles(width: int, height: int, args: "RtRenderArgs") -> np.ndarray:

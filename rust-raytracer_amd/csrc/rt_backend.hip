@@ -17,10 +17,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -963,6 +965,21 @@ extern "C" int rt_render_device(RtBackend *be, const RtDeviceScene *ds, const Rt
     return render_impl(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, stats_out);
 }
 
+namespace {
+
+// Grows the backend's scratch framebuffer to at least `floats`.
+int ensure_scratch_fb(RtBackend *be, size_t floats) {
+    if (be->fb_floats >= floats) return RT_OK;
+    if (be->fb) (void)hipFree(be->fb);
+    be->fb = nullptr;
+    be->fb_floats = 0;
+    RT_HIP(hipMalloc((void **)&be->fb, floats * sizeof(float)));
+    be->fb_floats = floats;
+    return RT_OK;
+}
+
+}  // namespace
+
 extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb,
                          const RtRayIds *ids_host, RtStats *stats_out) {
     if (!be || !ds || !args || !fb_rgb) return rt::set_error(RT_ERR_INVALID, "null argument");
@@ -976,13 +993,7 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
     const uint32_t tiles_x = ((uint32_t)W + tw - 1) / tw, tiles_y = ((uint32_t)H + th - 1) / th;
     // a partitioned render lands tile-major (edge tiles padded), so size for whole tiles
     const size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
-    if (be->fb_floats < dev_floats) {
-        if (be->fb) (void)hipFree(be->fb);
-        be->fb = nullptr;
-        be->fb_floats = 0;
-        RT_HIP(hipMalloc((void **)&be->fb, dev_floats * sizeof(float)));
-        be->fb_floats = dev_floats;
-    }
+    if (int grown = ensure_scratch_fb(be, dev_floats)) return grown;
     RT_HIP(hipMemsetAsync(be->fb, 0, fb_floats * sizeof(float), be->stream));
 
     // device mirrors of the requested id arrays
@@ -1060,6 +1071,95 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
         }
     }
     cleanup();
+    return RT_OK;
+}
+
+extern "C" int rt_render_multi(RtBackend *const *bes, RtDeviceScene *const *dss, uint32_t n, const RtRenderArgs *args,
+                               float *fb_rgb, RtStats *stats_out) {
+    if (!bes || !dss || !args || !fb_rgb || n == 0) return rt::set_error(RT_ERR_INVALID, "null argument");
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!bes[k] || !dss[k]) return rt::set_error(RT_ERR_INVALID, "null backend or scene");
+        if (dss[k]->width != dss[0]->width || dss[k]->height != dss[0]->height)
+            return rt::set_error(RT_ERR_INVALID, "the scenes of the parts differ in size");
+        for (uint32_t j = 0; j < k; ++j)
+            if (bes[j] == bes[k]) return rt::set_error(RT_ERR_INVALID, "every part needs a backend of its own");
+    }
+    if (n == 1) {
+        RtRenderArgs a = *args;
+        a.part_index = 0;
+        a.part_count = 1;
+        return rt_render(bes[0], dss[0], &a, fb_rgb, nullptr, stats_out);
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    const uint32_t W = dss[0]->width, H = dss[0]->height;
+    RtRenderArgs a0 = *args;
+    a0.part_index = 0;
+    a0.part_count = n;
+    a0.progress = nullptr;
+    uint32_t stride = 0;
+    int rc = rt_partition_info(W, H, &a0, nullptr, nullptr, &stride);
+    if (rc) return rc;
+    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+    const size_t block_floats = (size_t)stride * tw * th * 3;
+
+    // one host thread per part: each renders into its backend's scratch buffer and waits for it
+    std::vector<int> part_rc(n, RT_OK);
+    std::vector<std::string> part_msg(n);
+    std::vector<RtStats> part_stats(n);
+    std::vector<std::thread> workers;
+    for (uint32_t k = 0; k < n; ++k)
+        workers.emplace_back([&, k]() {
+            RtRenderArgs a = a0;
+            a.part_index = k;
+            int r = hipSetDevice(bes[k]->device) == hipSuccess ? RT_OK : rt::set_error(RT_ERR_DEVICE, "hipSetDevice failed");
+            if (!r) r = ensure_scratch_fb(bes[k], block_floats);
+            if (!r) r = render_impl(bes[k], dss[k], &a, bes[k]->fb, nullptr, bes[k]->stream, &part_stats[k]);
+            part_rc[k] = r;
+            if (r) part_msg[k] = rt::last_error_slot();  // the slot is per thread
+        });
+    for (auto &w : workers) w.join();
+    for (uint32_t k = 0; k < n; ++k)
+        if (part_rc[k]) return rt::set_error(part_rc[k], "part " + std::to_string(k) + ": " + part_msg[k]);
+
+    // the parts' tiles, end to end on the first backend's device, then the image layout
+    RtBackend *root = bes[0];
+    RT_HIP(hipSetDevice(root->device));
+    float *gathered = nullptr, *frame = nullptr;
+    auto release = [&]() {
+        if (gathered) (void)hipFree(gathered);
+        if (frame) (void)hipFree(frame);
+    };
+    const size_t fb_floats = (size_t)W * H * 3;
+    if (hipMalloc((void **)&gathered, (size_t)n * block_floats * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&frame, fb_floats * sizeof(float)) != hipSuccess) {
+        release();
+        return rt::set_error(RT_ERR_DEVICE, "hipMalloc of the gather buffers failed");
+    }
+    for (uint32_t k = 0; k < n; ++k)
+        if (hipMemcpy(gathered + (size_t)k * block_floats, bes[k]->fb, block_floats * sizeof(float), hipMemcpyDefault) != hipSuccess) {
+            release();
+            return rt::set_error(RT_ERR_DEVICE, "copy of part " + std::to_string(k) + " to the first device failed");
+        }
+    rc = rt_untile_device(root, W, H, &a0, gathered, frame, root->stream);
+    if (!rc && (hipStreamSynchronize(root->stream) != hipSuccess ||
+                hipMemcpy(fb_rgb, frame, fb_floats * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = rt::set_error(RT_ERR_DEVICE, "un-tile or copy to the host failed");
+    release();
+    if (rc) return rc;
+    if (stats_out) {
+        std::memset(stats_out, 0, sizeof(*stats_out));
+        for (const RtStats &p : part_stats) {
+            stats_out->primary_rays += p.primary_rays;
+            stats_out->secondary_rays += p.secondary_rays;
+            stats_out->shadow_rays += p.shadow_rays;
+            stats_out->shaded_hits += p.shaded_hits;
+            for (int c = 0; c < RT_K_COUNT; ++c) {
+                stats_out->kernel_ms[c] += p.kernel_ms[c];
+                stats_out->kernel_launches[c] += p.kernel_launches[c];
+            }
+        }
+        stats_out->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
     return RT_OK;
 }
 

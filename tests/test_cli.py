@@ -84,6 +84,15 @@ def test_cli_renders_what_the_library_renders(cli, rt, backend, scene_path, tmp_
     assert s["primary_rays"] == st.primary_rays == 120 * 80 * 9
     assert s["shadow_rays"] == st.shadow_rays and s["secondary_rays"] == st.secondary_rays
     dev.close()
+    # --gpus N: the frame split over N backends in one process (here all on the one device) is the same frame
+    multi = str(tmp_path / "multi.png")
+    for gpus in ("3", "6"):
+        rc, err = run(cli, "-i", scene_path("mixed_features"), "-o", multi, "-x", "120", "-y", "80", "-r", "9", "-d", "4",
+                      "--gpus", gpus, "--same-device", "--stats-json", stats)
+        assert rc == 0, err
+        assert np.array_equal(np.asarray(Image.open(multi).convert("RGB")), np.asarray(Image.open(out).convert("RGB")))
+        s = json.load(open(stats))
+        assert s["primary_rays"] == 120 * 80 * 9 and s["shadow_rays"] == st.shadow_rays
     # defaults: 360x360, 4 rays per pixel, depth 3 (prelude.rs:54-57)
     rc, err = run(cli, "-i", scene_path("simple_sphere_scene"), "-o", out)
     assert rc == 0, err

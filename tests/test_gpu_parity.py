@@ -183,6 +183,26 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
     dev.close()
 
 
+@pytest.mark.parametrize("n,weight", [(2, 0), (5, 6)])
+def test_render_multi_in_one_process(rt, scene_path, n, weight):
+    """rt_render_multi: n backends (here on one device), one host thread each, tiles collected on the first:
+    the frame and the ray counts of the unsplit render."""
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=250, image_height=170, recursion_depth=6)
+    backends = [rt.Backend(0) for _ in range(n)]
+    devs = [b.upload(scene) for b in backends]
+    whole, _, whole_stats = devs[0].render(2)
+    a = devs[0].render_args(2, tile=(16, 16), part0_weight=weight)
+    fb, stats = rt.render_multi(devs, a)
+    assert np.array_equal(fb, whole.pixels)
+    assert stats.total_rays() == whole_stats.total_rays()
+    with pytest.raises(rt.RtError):  # a backend twice
+        rt.render_multi([devs[0], devs[0]], a)
+    for d in devs:
+        d.close()
+    for b in backends:
+        b.close()
+
+
 def test_untile_of_frames_gathered_together(rt, backend, scene_path):
     """A gather that brings several frames at once leaves rank 0 with [rank][frame][block]:
     rt_untile_device_pitched restores frame f from offset f blocks with the ranks' blocks F blocks apart."""
