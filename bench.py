@@ -50,6 +50,20 @@ def algorithmic_bytes(workload):
         return None
 
 
+def measured_counters(workload, kernel_class):
+    """Counter figures of the dominant kernel from the committed PMC profile of this same command
+    (profiles/pmc_traffic.json): HBM GB/s actually moved, L2 hit rate, VALU lane utilisation; or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f).get(workload)
+        if measured_traffic(workload, kernel_class) is None:
+            return None
+        return {k: entry.get(k) for k in ("hbm_gbs", "l2_hit_rate", "valu_lane_utilisation")}
+    except Exception:
+        return None
+
+
 def measured_traffic(workload, kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
     command (profiles/pmc_traffic.json, written by tools/summarize_pmc.py), or None."""
@@ -349,6 +363,8 @@ def main():
             alone_ms = k_ms[dom] / max(k_n[dom], 1)
             alone = bytes_per_launch / (alone_ms * 1e-3) / 1e9
             roofline["alone_on_the_gpu"] = {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS}
+            if not multi:
+                roofline["counters"] = measured_counters(args.workload, dom_name)  # rocprofv3 --pmc passes, profiles/
             if not multi:
                 torch.cuda.set_stream(torch.cuda.default_stream())
                 hbm = measured_hbm_gbs(torch)

@@ -96,6 +96,8 @@ def main():
             dd = timed[dom]["derived"]
             table[workload] = {"kernel": dom, "hbm_read_bytes": dd["hbm_read_bytes"], "hbm_write_bytes": dd["hbm_write_bytes"],
                                "bytes": dd["hbm_read_bytes"] + dd["hbm_write_bytes"], "avg_us": timed[dom]["avg_us"],
+                               "hbm_gbs": (dd["hbm_read_bytes"] + dd["hbm_write_bytes"]) / (timed[dom]["avg_us"] * 1e-6) / 1e9,
+                               "l2_hit_rate": dd.get("l2_hit_rate"), "valu_lane_utilisation": dd.get("valu_lane_utilisation"),
                                "source": root}
             with open(path, "w") as f:
                 json.dump(table, f, indent=1)
