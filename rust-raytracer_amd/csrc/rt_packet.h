@@ -69,6 +69,19 @@ __device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav (&s)[R]
     return (nx > half ? 1u : 0u) | (ny > half ? 2u : 0u) | (nz > half ? 4u : 0u) | (mixed ? 8u : 0u);
 }
 
+// Scene records (nodes, triangles, scene-level primitives) are read through the constant address
+// space: nothing writes them while a kernel runs.  A wave-uniform fetch from a plain global pointer
+// is a scalar load only as long as the compiler can prove that no store of the kernel aliases it;
+// anything it cannot see through (a store in a loop around the walk, a builtin that counts as a
+// memory clobber) silently turns every record fetch into per-lane vector loads, 2-5x slower.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) rt_f4 *rt_scene_f4;
+#define RT_SCENE_F4(p) ((rt_scene_f4)(p))
+#else
+typedef const rt_f4 *rt_scene_f4;
+#define RT_SCENE_F4(p) (reinterpret_cast<const rt_f4 *>(p))
+#endif
+
 // Inner nodes until a leaf (or the end) comes up.  OCT 0..7: all live rays of the wave have these
 // direction signs (bit k = negative on axis k), which turns the twelve min / max that sort each
 // slab's two plane distances into register choices made at compile time; OCT 8: mixed signs, the
@@ -78,7 +91,7 @@ __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastT
                                                uint32_t dir_bits) {
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
     while (cur >= 0) {
-        const rt_f4 *n = reinterpret_cast<const rt_f4 *>(node_base + (uint32_t)cur);
+        const rt_scene_f4 n = RT_SCENE_F4(node_base + (uint32_t)cur);
         const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
         bool hl = false, hr = false;
 #pragma unroll
@@ -188,7 +201,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
             uint32_t at = first * (uint32_t)sizeof(RtTriXf);
             for (uint32_t k = 0; k < cnt; ++k, at += (uint32_t)sizeof(RtTriXf)) {
                 const int32_t gtri = (int32_t)(first + k);
-                const rt_f4 *tp = reinterpret_cast<const rt_f4 *>(tri_base + at);
+                const rt_scene_f4 tp = RT_SCENE_F4(tri_base + at);
                 const rt_f4 uv0 = tp[0], uv1 = tp[1], tn = tp[2];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -208,7 +221,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
         }
         bool entered = false;
         for (uint32_t k = 0; k < cnt && !entered; ++k) {
-            const rt_f4 *pp = S.tprims + (size_t)(first + k) * 4;
+            const rt_scene_f4 pp = RT_SCENE_F4(S.tprims + (size_t)(first + k) * 4);
             const rt_f4 h = pp[0];
             const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
                           proto_type = rt_as_int(h.w);
@@ -228,7 +241,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                 if (k + 1 < cnt) stk.push(rt_make_leaf_ref(first + k + 1, cnt - k - 1));
                 stk.push(RT_REF_EXIT_BLAS);
                 if (is_inst) {
-                    const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
+                    const rt_scene_f4 m = RT_SCENE_F4(S.tprim_xf + (size_t)(first + k) * 3);
                     const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
