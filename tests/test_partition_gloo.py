@@ -1,8 +1,10 @@
-"""Two ranks over gloo rehearse the multi-GPU frame protocol on the CPU: each rank renders
+"""Ranks over gloo rehearse the multi-GPU frame protocol on the CPU: each rank renders
 the tiles it owns (the backend's stage bodies on the host), packs them into the compact
 tile-major part buffer that rt_render_device writes, one gather brings the part buffers to
 rank 0, and rank 0 rebuilds the frame the way rt_untile_device does.  The result must be
-bit-identical with the unpartitioned frame (static tile map, ordered per-pixel sums)."""
+bit-identical with the unpartitioned frame (static tile map, ordered per-pixel sums).  Variants:
+three ranks with a smaller share for rank 0 (RtRenderArgs.part0_weight), and several frames
+gathered with one collective, which rank 0 receives as [rank][frame][block]."""
 import os
 import socket
 import sys
@@ -39,7 +41,7 @@ def unpack_parts(gathered, tile_lists, tiles_x):
     return fb
 
 
-def worker(rank, world, port, result_path):
+def worker(rank, world, port, result_path, weight=0, frames=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -53,26 +55,36 @@ def worker(rank, world, port, result_path):
         sc = rt.parse_scene_file(os.path.join(ROOT, "scenes", "mixed_features.json"), image_width=W, image_height=H,
                                  recursion_depth=6)
         a = rt.RtRenderArgs()
-        a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count = N, TILE, TILE, rank, world
+        a.sqrt_rays_per_pixel, a.tile_w, a.tile_h, a.part_index, a.part_count, a.part0_weight = N, TILE, TILE, rank, world, weight
         total, owned, stride = C_partition_info(rt, a)
         tiles_x = (W + TILE - 1) // TILE
         tiles = rt.partition_tiles(W, H, a)
         assert tiles.size == owned
-        fb, _, stats = HS.render(sc, N, want_ids=False, tile=(TILE, TILE), part=(rank, world))
-        part = torch.from_numpy(pack_part(fb, tiles, tiles_x, stride))
-        rays = torch.tensor([float(stats.total_rays())], dtype=torch.float64)
+        # frame f: jittered sampling with seed f, so that the frames of a group differ (frame 0: the regular grid)
+        mine, n_rays = [], 0.0
+        for f in range(frames):
+            fb, _, stats = HS.render(sc, N, want_ids=False, tile=(TILE, TILE), part=(rank, world), part0_weight=weight,
+                                     aa=1 if f else 0, seed=f)
+            mine.append(pack_part(fb, tiles, tiles_x, stride))
+            n_rays += stats.total_rays()
+        part = torch.from_numpy(np.stack(mine))  # [frame][block]: what one rank sends
+        rays = torch.tensor([n_rays], dtype=torch.float64)
         bufs = [torch.zeros_like(part) for _ in range(world)] if rank == 0 else None
-        dist.gather(part, bufs, dst=0)
+        dist.gather(part, bufs, dst=0)  # ONE collective for all frames
         dist.all_reduce(rays)
         if rank == 0:
             lists = []
             for p in range(world):
                 a.part_index = p
                 lists.append(rt.partition_tiles(W, H, a))
-            frame = unpack_parts([b.numpy() for b in bufs], lists, tiles_x)
-            full, _, full_stats = HS.render(sc, N, want_ids=False, tile=(TILE, TILE))
-            np.savez(result_path, same=np.array_equal(frame, full), rays=rays.item(), full_rays=full_stats.total_rays(),
-                     covered=sum(len(l) for l in lists), total=total)
+            same, full_rays = True, 0
+            for f in range(frames):  # rank 0 holds [rank][frame][block]
+                frame = unpack_parts([b.numpy()[f] for b in bufs], lists, tiles_x)
+                full, _, full_stats = HS.render(sc, N, want_ids=False, tile=(TILE, TILE), aa=1 if f else 0, seed=f)
+                same = same and np.array_equal(frame, full)
+                full_rays += full_stats.total_rays()
+            np.savez(result_path, same=same, rays=rays.item(), full_rays=full_rays,
+                     covered=sum(len(l) for l in lists), total=total, sizes=np.array([len(l) for l in lists]))
     finally:
         dist.destroy_process_group()
 
@@ -86,7 +98,8 @@ def C_partition_info(rt, a):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gather_rebuilds_the_frame(tmp_path):
+@pytest.mark.parametrize("world,weight,frames", [(2, 0, 1), (3, 5, 2)])
+def test_gather_rebuilds_the_frame(tmp_path, world, weight, frames):
     import hostsim_lib as HS
 
     HS.lib()  # build the simulator once, before the ranks race to
@@ -94,8 +107,11 @@ def test_two_rank_gather_rebuilds_the_frame(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     result = str(tmp_path / "result.npz")
-    mp.spawn(worker, args=(2, port, result), nprocs=2, join=True)
+    mp.spawn(worker, args=(world, port, result, weight, frames), nprocs=world, join=True)
     r = np.load(result)
     assert bool(r["same"])
     assert r["covered"] == r["total"]
-    assert r["rays"] == r["full_rays"]  # the parts traced exactly the rays of the whole frame
+    assert r["rays"] == r["full_rays"]  # the parts traced exactly the rays of the whole frames
+    if weight:
+        # rank 0 took the smaller share (35 tiles over 21 lanes: the shares are coarse on this small grid)
+        assert r["sizes"][0] <= r["sizes"][1:].min() and r["sizes"][0] < r["sizes"][1:].mean()
