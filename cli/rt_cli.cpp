@@ -207,7 +207,10 @@ int main(int argc, char **argv) {
     if (gpus > 1) {
         ra.tile_w = ra.tile_h = 32;
         ra.part0_weight = gpus > 4 ? 7 : 0;  // the first device also collects the tiles
-        rc = rt_render_multi(all_be.data(), all_ds.data(), (uint32_t)gpus, &ra, fb.data(), &st);
+        RtMulti *multi = nullptr;
+        rc = rt_multi_create(all_be.data(), all_ds.data(), (uint32_t)gpus, &multi);
+        if (rc == RT_OK) rc = rt_render_multi(multi, &ra, fb.data(), &st);
+        rt_multi_destroy(multi);
     } else {
         rc = rt_render(be, ds, &ra, fb.data(), dump_ids.empty() ? nullptr : &ids, &st);
     }

@@ -21,6 +21,7 @@
 #ifndef RT_HIP_H
 #define RT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "rt_scene.h"
@@ -35,7 +36,7 @@ extern "C" {
 #define RT_ERR_UNSUPPORTED (-3) /* the reference panics here (unimplemented!()), or a limit of this
                                    library (GGXMirror beyond recursion depth 16, trees too deep
                                    for the LDS traversal stack, an image format other than PNG) */
-#define RT_ERR_DEVICE (-4)      /* HIP runtime failure */
+#define RT_ERR_DEVICE (-4)      /* HIP or RCCL runtime failure */
 #define RT_ERR_IO (-5)          /* file could not be read */
 
 /* ------------------------------------------------------------------ */
@@ -89,6 +90,18 @@ void rt_backend_destroy(RtBackend *backend);
  * has zero thickness is never entered, geometry/bbox.rs:89,104,119). */
 int rt_scene_upload(RtBackend *backend, const RtScene *scene, RtDeviceScene **dev_scene_out);
 void rt_scene_free(RtDeviceScene *dev_scene);
+
+/* rt_scene_upload with build options (NULL or all zero = rt_scene_upload).
+ * RT_UPLOAD_REFERENCE_MESH_TREES: RT_MODE_FAST walks the reference's mesh trees
+ * (geometry/mesh.rs:59) instead of surface-area trees of its own; same hits, for
+ * comparing the two. */
+enum { RT_UPLOAD_REFERENCE_MESH_TREES = 1 };
+typedef struct RtUploadOptions {
+    uint32_t flags; /* RT_UPLOAD_* */
+    uint32_t _reserved[3];
+} RtUploadOptions;
+int rt_scene_upload_with(RtBackend *backend, const RtScene *scene, const RtUploadOptions *options,
+                         RtDeviceScene **dev_scene_out);
 
 /* ------------------------------------------------------------------ */
 /* render                                                               */
@@ -154,7 +167,23 @@ typedef struct RtRenderArgs {
      * enqueues. */
     void (*progress)(uint64_t pixels_done, uint64_t pixels_total, void *user);
     void *progress_user;
+    /* Tuning; 0 = the library's choice everywhere.  None of them changes a pixel.
+     *  batch_samples  most samples (pixels x rays per pixel) worked on at a time; a larger frame is
+     *                 rendered in several batches of whole tiles (0 -> 16 Mi, about 1.9 GB of queues)
+     *  xcd_chunk      consecutive 256-sample blocks handed to one XCD (one L2) at a time
+     *  flags          RT_RENDER_* below */
+    uint32_t batch_samples;
+    uint32_t xcd_chunk;
+    uint32_t flags;
+    uint32_t _reserved;
 } RtRenderArgs;
+
+enum {
+    RT_RENDER_NO_PACKETS = 1,       /* RT_MODE_FAST: one ray per lane for camera and shadow rays too */
+    RT_RENDER_ROW_MAJOR_PIXELS = 2, /* work the pixels of a tile row by row instead of in small blocks */
+    RT_RENDER_UNFUSED_SHADOWS = 4   /* RT_MODE_FAST: one shadow-ray launch per light and a separate launch for the
+                                       light sums, instead of one kernel for both */
+};
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is
  *   s = (i + j * width) * n*n + p * n + q     (render.rs:64-65 loop order).
@@ -203,6 +232,25 @@ typedef struct RtStats {
 int rt_render(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
               float *fb_rgb, const RtRayIds *ids_host, RtStats *stats_out);
 
+/* Page-locked host memory for framebuffers (no counterpart in the reference, whose Framebuffer is
+ * a Vec): the device writes a frame into such memory directly, at the speed of the bus.  rt_render
+ * recognises it (and any other memory registered with the HIP runtime) and skips its staging copy;
+ * rt_render_async requires it. */
+int rt_host_alloc(size_t bytes, void **ptr_out);
+void rt_host_free(void *ptr);
+
+/* render (render.rs:7-23) without waiting: enqueues the frame and its copy into `fb_rgb_pinned`
+ * (page-locked host memory, width*height*3 floats, whole frames only: part_count <= 1) on the
+ * backend's stream and returns.  rt_backend_sync waits for it.  With one backend per frame in
+ * flight the copy of frame k over the bus overlaps the kernels of frame k+1. */
+int rt_render_async(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
+                    float *fb_rgb_pinned);
+
+/* Waits for everything enqueued through this backend (rt_render_async, rt_render_device without
+ * stats_out) and reports what only the device could notice: RT_ERR_DEVICE if a kernel failed or a
+ * frame since the last check was cut short (traversal stack overflow, an internal error). */
+int rt_backend_sync(RtBackend *backend);
+
 /* Same, but `fb_rgb_dev` and the `ids_dev` arrays are DEVICE pointers and the
  * work is enqueued on `hip_stream` (a hipStream_t, NULL = the backend's own
  * stream, which is created non-blocking: work on it is NOT ordered with the
@@ -250,16 +298,37 @@ int rt_untile_device_pitched(RtBackend *backend, uint32_t width, uint32_t height
                              const float *gathered_dev, size_t part_pitch_floats, float *fb_rgb_dev,
                              void *hip_stream);
 
-/* render (render.rs:7-23) with the frame split over `n` backends in ONE process -- what a
- * front end with a `--gpus N` flag calls.  backends[k] / dev_scenes[k] (the same scene, uploaded
- * through backends[k]) render part k of n concurrently, one host thread each; the parts' tiles
- * are then copied to backends[0]'s device (peer copies), un-tiled there and returned in host
- * memory like rt_render's.  args->part_index / part_count are ignored (set per part),
- * part0_weight is honoured, progress is not called.  The backends may sit on different devices
- * or share one.  stats_out (may be NULL): ray counts and kernel times summed over the parts,
- * render_ms = wall time of the whole call.  n = 1 is rt_render. */
-int rt_render_multi(RtBackend *const *backends, RtDeviceScene *const *dev_scenes, uint32_t n,
-                    const RtRenderArgs *args, float *fb_rgb, RtStats *stats_out);
+/* render (render.rs:7-23) with the frame split over several backends in ONE process -- what a
+ * front end with a `--gpus N` flag calls.  An RtMulti binds n backends and the same scene uploaded
+ * through each (backends[k] / dev_scenes[k] render part k of n); the backends may sit on
+ * different devices or share one.  It owns what a frame needs beyond the backends: one host thread
+ * per part that enqueues the part's kernels, the gather buffers on backends[0]'s device, and an
+ * RCCL communicator with one rank per distinct device (ncclCommInitAll; librccl is loaded when the
+ * first RtMulti or RtComm is created, not with this library).
+ * rt_render_multi: every part renders its tiles (part 0 straight into the gather buffer), ONE
+ * grouped ncclSend / ncclRecv brings the other parts' tiles to backends[0]'s device over xGMI,
+ * a kernel there restores the image layout, and the frame is returned in host memory like
+ * rt_render's.  args->part_index / part_count are ignored (set per part), part0_weight is
+ * honoured, progress is not called.  stats_out (may be NULL): ray counts and kernel times summed
+ * over the parts (this waits for every part), render_ms = wall time of the call. */
+typedef struct RtMulti RtMulti;
+int rt_multi_create(RtBackend *const *backends, RtDeviceScene *const *dev_scenes, uint32_t n, RtMulti **multi_out);
+void rt_multi_destroy(RtMulti *multi);
+int rt_render_multi(RtMulti *multi, const RtRenderArgs *args, float *fb_rgb, RtStats *stats_out);
+
+/* The same gather for a launcher with ONE PROCESS PER GPU (MPI, torch.distributed): rank 0 makes
+ * an id and hands it to the other ranks by whatever means the launcher has, every rank creates its
+ * end of the communicator (ncclCommInitRank) on its backend's device, and rt_comm_gather enqueues
+ * on `hip_stream`: this rank's `floats` floats at `part_dev` go to rank 0, which receives rank r's
+ * at gathered_dev + r * floats (gathered_dev is ignored on the other ranks).  Collective: every
+ * rank must call it, with the same `floats`. */
+#define RT_COMM_ID_BYTES 128
+typedef struct RtComm RtComm;
+int rt_comm_id(uint8_t id_out[RT_COMM_ID_BYTES]);
+int rt_comm_create(RtBackend *backend, const uint8_t id[RT_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+                   RtComm **comm_out);
+void rt_comm_destroy(RtComm *comm);
+int rt_comm_gather(RtComm *comm, const float *part_dev, size_t floats, float *gathered_dev, void *hip_stream);
 
 /* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
  * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).

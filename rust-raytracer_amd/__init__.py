@@ -37,6 +37,11 @@ RT_ERR_IO = -5
 
 RT_MODE_FAST = 0
 RT_MODE_REFERENCE_ORDER = 1
+RT_RENDER_NO_PACKETS = 1
+RT_RENDER_ROW_MAJOR_PIXELS = 2
+RT_RENDER_UNFUSED_SHADOWS = 4
+RT_UPLOAD_REFERENCE_MESH_TREES = 1
+RT_COMM_ID_BYTES = 128
 RT_K_COUNT = 8
 KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_shadow", "accumulate", "resolve")
 
@@ -171,7 +176,15 @@ class RtRenderArgs(C.Structure):
         ("seed", C.c_uint64),
         ("progress", C.c_void_p),
         ("progress_user", C.c_void_p),
+        ("batch_samples", C.c_uint32),
+        ("xcd_chunk", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("_reserved", C.c_uint32),
     ]
+
+
+class RtUploadOptions(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
 
 
 class RtRayIds(C.Structure):
@@ -255,7 +268,21 @@ def lib() -> C.CDLL:
     L.rt_scene_free.restype = None
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), C.POINTER(RtStats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp, C.POINTER(RtStats)]
-    L.rt_render_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(RtRenderArgs), vp, C.POINTER(RtStats)]
+    L.rt_scene_upload_with.argtypes = [vp, C.POINTER(RtScene), C.POINTER(RtUploadOptions), C.POINTER(vp)]
+    L.rt_render_async.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp]
+    L.rt_backend_sync.argtypes = [vp]
+    L.rt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.rt_host_free.argtypes = [vp]
+    L.rt_host_free.restype = None
+    L.rt_multi_create.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(vp)]
+    L.rt_multi_destroy.argtypes = [vp]
+    L.rt_multi_destroy.restype = None
+    L.rt_render_multi.argtypes = [vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtStats)]
+    L.rt_comm_id.argtypes = [vp]
+    L.rt_comm_create.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.rt_comm_destroy.argtypes = [vp]
+    L.rt_comm_destroy.restype = None
+    L.rt_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.rt_collect_timings.argtypes = [vp, C.POINTER(RtStats)]
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
     L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
@@ -277,16 +304,121 @@ def _check(rc: int) -> None:
         raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
 
 
-def render_multi(dev_scenes, args: "RtRenderArgs"):
-    """rt_render_multi: one frame split over the given DeviceScenes (one backend each).  Returns (pixels, RtStats)."""
-    n = len(dev_scenes)
-    bes = (C.c_void_p * n)(*[d.backend.handle for d in dev_scenes])
-    dss = (C.c_void_p * n)(*[d._h for d in dev_scenes])
-    W, H = dev_scenes[0].width, dev_scenes[0].height
-    fb = np.zeros((H, W, 3), np.float32)
-    stats = RtStats()
-    _check(lib().rt_render_multi(bes, dss, n, C.byref(args), fb.ctypes.data, C.byref(stats)))
-    return fb, stats
+def _share_rccl_with_torch() -> None:
+    """The communicators below load librccl by its soname when the first one is made.  A PyTorch wheel
+    bundles a copy (torch/lib/librccl.so) built against its bundled HIP runtime; when that runtime is
+    the one this process holds (see _share_hip_runtime_with_torch), its RCCL must be the one as well,
+    so it is loaded first and the library finds it already mapped."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+class Multi:
+    """rt_multi_create / rt_render_multi: one frame split over the given DeviceScenes (one backend each),
+    the parts' tiles gathered on the first one's device over RCCL."""
+
+    def __init__(self, dev_scenes):
+        lib()
+        _share_rccl_with_torch()
+        n = len(dev_scenes)
+        self.dev_scenes = list(dev_scenes)
+        bes = (C.c_void_p * n)(*[d.backend.handle for d in dev_scenes])
+        dss = (C.c_void_p * n)(*[d._h for d in dev_scenes])
+        self._h = C.c_void_p()
+        _check(lib().rt_multi_create(bes, dss, n, C.byref(self._h)))
+
+    def render(self, args: "RtRenderArgs", out: Optional[np.ndarray] = None, want_stats: bool = True):
+        """Returns (pixels [H, W, 3] float32, RtStats | None).  `out` may be a page-locked array (HostBuffer)."""
+        W, H = self.dev_scenes[0].width, self.dev_scenes[0].height
+        fb = np.zeros((H, W, 3), np.float32) if out is None else out
+        stats = RtStats() if want_stats else None
+        _check(lib().rt_render_multi(self._h, C.byref(args), fb.ctypes.data, C.byref(stats) if stats is not None else None))
+        return fb, stats
+
+    def close(self) -> None:
+        if self._h:
+            lib().rt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """rt_comm_*: this process's end of the RCCL communicator of a one-process-per-GPU launch."""
+
+    @staticmethod
+    def make_id() -> bytes:
+        lib()
+        _share_rccl_with_torch()
+        buf = (C.c_uint8 * RT_COMM_ID_BYTES)()
+        _check(lib().rt_comm_id(buf))
+        return bytes(buf)
+
+    def __init__(self, backend: "Backend", comm_id: bytes, rank: int, world: int):
+        lib()
+        _share_rccl_with_torch()
+        assert len(comm_id) == RT_COMM_ID_BYTES
+        buf = (C.c_uint8 * RT_COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        _check(lib().rt_comm_create(backend.handle, buf, rank, world, C.byref(self._h)))
+
+    def gather(self, part_dev_ptr: int, floats: int, gathered_dev_ptr: int, stream: int = 0) -> None:
+        _check(lib().rt_comm_gather(self._h, part_dev_ptr, floats, gathered_dev_ptr or None, stream or None))
+
+    def close(self) -> None:
+        if self._h:
+            lib().rt_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostBuffer:
+    """rt_host_alloc: page-locked host memory as a float32 numpy array of the given shape."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(x) for x in shape)
+        count = int(np.prod(self.shape))
+        self._p = C.c_void_p()
+        _check(lib().rt_host_alloc(count * 4, C.byref(self._p)))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_float)), shape=(count,)).reshape(self.shape)
+
+    @property
+    def ptr(self) -> int:
+        return self._p.value
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            lib().rt_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def partition_tiles(width: int, height: int, args: "RtRenderArgs") -> np.ndarray:
@@ -432,10 +564,20 @@ class Backend:
         _check(lib().rt_collect_timings(self._h, C.byref(st)))
         return st
 
-    def upload(self, scene: Scene) -> "DeviceScene":
+    def upload(self, scene: Scene, flags: int = 0) -> "DeviceScene":
+        """rt_scene_upload; with `flags` (RT_UPLOAD_*) rt_scene_upload_with."""
         h = C.c_void_p()
-        _check(lib().rt_scene_upload(self._h, scene.ptr, C.byref(h)))
+        if flags:
+            opts = RtUploadOptions()
+            opts.flags = int(flags)
+            _check(lib().rt_scene_upload_with(self._h, scene.ptr, C.byref(opts), C.byref(h)))
+        else:
+            _check(lib().rt_scene_upload(self._h, scene.ptr, C.byref(h)))
         return DeviceScene(self, scene, h)
+
+    def sync(self) -> None:
+        """rt_backend_sync: waits for what was enqueued through this backend and raises if a frame failed on the device."""
+        _check(lib().rt_backend_sync(self._h))
 
     def close(self) -> None:
         if self._h:
@@ -474,8 +616,9 @@ class DeviceScene:
             pass
 
     def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-                    tile=(0, 0), part=(0, 1), seed=0, part0_weight=0) -> RtRenderArgs:
+                    tile=(0, 0), part=(0, 1), seed=0, part0_weight=0, batch_samples=0, xcd_chunk=0, flags=0) -> RtRenderArgs:
         a = RtRenderArgs()
+        a.batch_samples, a.xcd_chunk, a.flags = int(batch_samples), int(xcd_chunk), int(flags)
         a.sqrt_rays_per_pixel = int(sqrt_rays_per_pixel)
         a.antialias_method = int(antialias_method)
         a.mode = int(mode)
@@ -486,26 +629,35 @@ class DeviceScene:
         return a
 
     def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None, part0_weight=0):
-        """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats).
+               want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None, part0_weight=0,
+               batch_samples=0, flags=0, want_stats: bool = True, out: Optional[np.ndarray] = None):
+        """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats|None).
         `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57);
-        `progress(pixels_done, pixels_total)` is called after every finished batch of tiles."""
-        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed, part0_weight)
+        `progress(pixels_done, pixels_total)` is called after every finished batch of tiles.
+        `want_stats=False` passes no RtStats: the frame is then enqueued without an event pair around
+        every kernel and waited for once.  `out`: render into this [H, W, 3] float32 array (e.g. a
+        HostBuffer's) instead of a fresh one."""
+        a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed, part0_weight,
+                             batch_samples=batch_samples, flags=flags)
         keep = None
         if progress is not None:
             keep = PROGRESS_FN(lambda done, total, _user: progress(int(done), int(total)))
             a.progress = C.cast(keep, C.c_void_p)
-        fb = Framebuffer(self.width, self.height)
+        fb = Framebuffer(self.width, self.height, out)
         ids = RayIds(self.width * self.height * int(sqrt_rays_per_pixel) ** 2, self.n_point_lights) if want_ids else None
         ids_struct = ids.as_struct() if ids is not None else None
-        stats = RtStats()
+        stats = RtStats() if want_stats else None
         _check(
             lib().rt_render(
                 self.backend.handle, self._h, C.byref(a), fb.pixels.ctypes.data,
-                C.byref(ids_struct) if ids_struct is not None else None, C.byref(stats),
+                C.byref(ids_struct) if ids_struct is not None else None, C.byref(stats) if stats is not None else None,
             )
         )
         return fb, ids, stats
+
+    def render_async(self, args: RtRenderArgs, host_buffer: "HostBuffer") -> None:
+        """rt_render_async: enqueue the frame and its copy into page-locked memory; Backend.sync() waits."""
+        _check(lib().rt_render_async(self.backend.handle, self._h, C.byref(args), host_buffer.ptr))
 
     def partition_info(self, args: RtRenderArgs):
         """(tiles_total, tiles_owned, tiles_owned_max) of a partitioned render."""

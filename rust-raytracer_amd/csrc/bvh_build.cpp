@@ -374,7 +374,7 @@ Tree build_tree(std::vector<BuildItem> items) {
     return tree;
 }
 
-std::string flatten_scene(const RtScene &scene, FlatScene &out) {
+std::string flatten_scene(const RtScene &scene, FlatScene &out, bool reference_mesh_trees) {
     out = FlatScene();
     if (scene.n_shapes == 0) return "scene has no shapes";
 
@@ -404,11 +404,10 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out) {
         // hundreds of overlapping boxes (bunny frame: the worst wave visits 304 nodes against 16 on
         // average); those rays set the run time of small launches.  As for the scene-level tree, it
         // holds exactly the triangles the reference can reach -- those of reference leaves whose box
-        // is not flat (bbox.rs:89,104,119) -- and its own flat boxes are widened.  RT_MESH_SAH=0 keeps
-        // the reference's tree in fast mode too, for comparison; a tree too deep for the traversal
+        // is not flat (bbox.rs:89,104,119) -- and its own flat boxes are widened.  `reference_mesh_trees`
+        // keeps the reference's tree in fast mode too, for comparison; a tree too deep for the traversal
         // stack's budget (a degenerate mesh) is dropped the same way.
-        bool own = true;
-        if (const char *e = std::getenv("RT_MESH_SAH")) own = std::atoi(e) != 0;
+        const bool own = !reference_mesh_trees;
         Tree fast;
         double pad = 0.0;
         if (own) {

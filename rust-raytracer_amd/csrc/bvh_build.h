@@ -60,7 +60,8 @@ struct FlatScene {
     std::vector<Tree> blas_fast;          // the fast mode's mesh trees; empty tree = the mesh keeps the reference's
 };
 
-// Returns "" on success, else a message.
-std::string flatten_scene(const RtScene &scene, FlatScene &out);
+// Returns "" on success, else a message.  `reference_mesh_trees`: the fast mode walks the
+// reference's mesh trees instead of surface-area trees of its own (RT_UPLOAD_REFERENCE_MESH_TREES).
+std::string flatten_scene(const RtScene &scene, FlatScene &out, bool reference_mesh_trees = false);
 
 }  // namespace rt

@@ -17,18 +17,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
-#include "../../include/rt_hip.h"
 #include "bvh_build.h"
-#include "rt_error.h"
-#include "rt_pipeline.h"
+#include "rt_backend_internal.h"
 #include "rt_packet.h"
 #include "rt_tree.h"
 // Register budgets (waves per SIMD the compiler must make room for; 512 VGPRs / waves).  These
@@ -48,7 +44,6 @@
 #endif
 #define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
 #define RT_PACKET_BLOCK 64
-#define RT_LIT_BLOCK 1024
 
 namespace {
 
@@ -121,6 +116,15 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         // mirror rays are sparse: compact them into the next bounce's queue
         const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, &Q.counters[RT_CNT_RAYS0 + bounce + 1]);
         if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, slot, tmp);
+        // Lit hits per chunk of RT_LIT_CHUNK samples, for the compaction of the lit table below.  At
+        // bounce 0 a wave holds 64 consecutive samples of one chunk: one add per wave.  Later bounces
+        // reach samples in queue order: one add per lit lane (rare, and spread over many addresses).
+        if (bounce == 0) {
+            const unsigned long long lit = __ballot(act == RT_ACT_LIT);
+            if (lit != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(lit));
+        } else if (act == RT_ACT_LIT) {
+            atomicAdd(&Q.block_counts[(uint32_t)Q.q_sample[bounce & 1][idx] / RT_LIT_CHUNK], 1u);
+        }
     }
 }
 
@@ -198,13 +202,71 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
     }
     const float tmin = KIND == 1 ? (float)RT_VERY_SMALL_NUMBER : closest_tmin(0);
     const bool ok = packet_traverse<KIND == 1, R>(S, st, tmin, lds, rows - 1);
-    if (!ok) Q.counters[RT_CNT_OVERFLOW] = 1;
+    if (!ok) *Q.overflow = 1;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (!live[k]) continue;
         if (KIND == 1) shadow_store(Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
         else closest_store(Q, base + (uint32_t)k * RT_PACKET_BLOCK, st[k].t, st[k].shape, st[k].tri);
     }
+}
+
+// Shadow rays AND the light sums of the lit hits in one kernel (fast mode): the wave takes 64 entries
+// of the lit list, walks the tree once per point light with their 64 shadow rays as a packet, keeps
+// one "hidden" bit per light and lane, and then adds up the lights in scene order as the accumulate
+// stage does.  Against one packet launch per light plus an accumulate launch this drops the
+// per-light blocker arrays (a write and a read of 4 B per ray), reads a hit's point, primitive and
+// origin ids once instead of once per light, and -- what matters most -- puts the f64 arithmetic of
+// the light sums into the issue slots that the tree walk of other waves leaves idle while it waits
+// for its node records.
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
+k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
+    extern __shared__ int32_t lds[];
+    const uint32_t count = Q.counters[RT_CNT_LIT];
+    const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
+    if (blockIdx.x >= n_blocks) return;
+    const uint32_t idx = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+    const int rows = S.stack_depth + 1;
+    const bool live = idx < count;
+    const uint32_t sample = live ? Q.lit_list[idx] : 0u;
+    int32_t org_shape = -1, org_tri = -1;
+    uint32_t hidden = 0u;
+    if (live) {
+        org_shape = RT_STREAM_LD(Q.l_shape[sample]);
+        org_tri = RT_STREAM_LD(Q.l_tri[sample]);
+        hidden = RT_STREAM_LD(Q.l_self[sample]);
+    }
+    const bool want_ids = ids.shadow_shape != nullptr || ids.shadow_tri != nullptr;
+    bool ok = true;
+    if (!S.disable_shadows) {
+        for (int ls = 0; ls < S.n_point_lights; ++ls) {
+            const bool self = ((hidden >> ls) & 1u) != 0u;
+            const bool trace = live && !self;
+            // the hit point is fetched again for every light rather than kept in six registers across the walk
+            D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
+            if (trace) {
+                o = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+                d = d3(S.lights[S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
+            }
+            FastTrav st[1];
+            fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
+            st[0].t = trace ? 1.0f : -__builtin_inff();  // Hit::to_light's bound, or an empty search interval
+            st[0].shape = -1;
+            st[0].tri = -1;
+            st[0].org_shape = org_shape;
+            st[0].org_tri = org_tri;
+            ok = packet_traverse<true, 1>(S, st, (float)RT_VERY_SMALL_NUMBER, lds, rows - 1) && ok;
+            if (st[0].shape >= 0) hidden |= 1u << ls;
+            if (want_ids && live) {
+                const size_t at = global_sample(B, sample) * (size_t)S.n_point_lights + (size_t)ls;
+                const int32_t blocker = self ? org_shape : st[0].shape;
+                if (ids.shadow_shape) ids.shadow_shape[at] = blocker;
+                if (ids.shadow_tri) ids.shadow_tri[at] = self ? -1 : tri_file_index(S, st[0].tri);
+            }
+        }
+    }
+    if (!ok) *Q.overflow = 1;
+    if (live) accumulate_masked(S, Q, sample, org_shape, S.disable_shadows ? 0u : hidden);
 }
 
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
@@ -230,10 +292,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffe
     }
 }
 
-// ---- compaction of the lit table into a list of sample indices, in sample order
-// (count per 1024-sample chunk -> exclusive scan of the chunk counts -> scatter).  Large chunks
-// keep the single-block scan in the middle short: it is pure latency on the frame's critical path.
-// No global atomics: thousands of waves adding to one counter serialise on it.
+// ---- compaction of the lit table into a list of sample indices, in sample order: the shade stage
+// has counted the lit hits of every chunk of RT_LIT_CHUNK samples; an exclusive scan of the chunk counts
+// and a scatter follow.  Large chunks keep the single-block scan in the middle short: it is pure
+// latency on the frame's critical path.  The list itself is filled without atomics (thousands of
+// waves taking slots from one counter serialise on it), so it comes out in sample order.
 //
 // A chunk is worked on by a 256-thread block in four rounds of 256 consecutive samples.  Blocks
 // of 1024 threads need sixteen free wave slots on ONE compute unit at once; with several frames
@@ -241,25 +304,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffe
 // leave that many, and these small kernels -- which every frame waits for -- sat in the queue
 // for hundreds of microseconds.
 
+#define RT_LIT_BLOCK RT_LIT_CHUNK
 #define RT_LIT_THREADS 256
 #define RT_LIT_ROUNDS (RT_LIT_BLOCK / RT_LIT_THREADS)
-
-__global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_count(RtBuffers Q, uint32_t n_samples) {
-    int mine = 0;
-    for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
-        const uint32_t s = blockIdx.x * RT_LIT_BLOCK + r * RT_LIT_THREADS + threadIdx.x;
-        mine += s < n_samples && Q.l_shape[s] >= 0 ? 1 : 0;
-    }
-    __shared__ int wave_sum[RT_LIT_THREADS / 64];
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
-    if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int w = 0; w < RT_LIT_THREADS / 64; ++w) n += wave_sum[w];
-        Q.block_counts[blockIdx.x] = (uint32_t)n;
-    }
-}
 
 // One block: block_counts[0..n_blocks) -> exclusive prefix sums in place, total -> counters[RT_CNT_LIT].
 __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scan(RtBuffers Q, uint32_t n_blocks) {
@@ -396,13 +443,6 @@ k_trace_user(RtSceneView S, uint64_t n, const double *o, const double *d, const 
 
 // ------------------------------------------------------------------ host side
 
-#define RT_HIP(call)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return rt::set_error(RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
 template <typename T>
 int dev_upload(const std::vector<T> &v, T **out) {
     *out = nullptr;
@@ -411,51 +451,6 @@ int dev_upload(const std::vector<T> &v, T **out) {
     RT_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return RT_OK;
 }
-
-}  // namespace
-
-struct RtEventPair {
-    hipEvent_t a, b;
-    int klass;
-};
-
-struct RtBackend {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    // event pairs of frames enqueued with RtRenderArgs::timed_classes, until rt_collect_timings
-    std::vector<RtEventPair> deferred;
-    hipStream_t deferred_stream = nullptr;
-    // batch buffers, grown on demand
-    RtBuffers buf{};
-    std::vector<void *> buf_allocs;
-    uint32_t buf_capacity = 0;
-    uint32_t buf_point_lights = 0;
-    // tile list of the last partition
-    int32_t *tile_list = nullptr;
-    std::vector<int32_t> tile_list_host;
-    uint32_t tile_key[6] = {0, 0, 0, 0, 0, 0};
-    // tile -> position lookup of rt_untile_device
-    uint32_t *tile_where = nullptr;
-    uint32_t untile_key[5] = {0, 0, 0, 0, 0};
-    // scratch framebuffer for rt_render
-    float *fb = nullptr;
-    size_t fb_floats = 0;
-};
-
-struct RtDeviceScene {
-    RtBackend *backend = nullptr;  // identity check only; may already be destroyed when the scene is freed
-    int device = 0;
-    RtSceneView view{};       // reference-order mode: the reference's scene-level tree
-    RtSceneView view_fast{};  // fast mode: the same arrays, entered through the fast mode's scene-level tree
-    std::vector<void *> allocs;
-    uint32_t width = 0, height = 0;
-    uint32_t n_point_lights = 0;
-    bool has_mirror = false;
-    bool has_lit = false;
-    bool has_ggx = false;  // a shape uses GGXMirror: frames go through the ray-tree kernel
-};
-
-namespace {
 
 void free_all(std::vector<void *> &v) {
     for (void *p : v)
@@ -501,13 +496,16 @@ int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
     }
     if ((rc = alloc_into(be->buf_allocs, &Q.l_shape, cap))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.l_tri, cap))) return rc;
+    if ((rc = alloc_into(be->buf_allocs, &Q.l_self, cap))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.occ_shape, cap * npl))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.occ_tri, cap * npl))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.occ_t, cap * npl))) return rc;
     if ((rc = alloc_into(be->buf_allocs, &Q.color, cap * 3))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.counters, (size_t)RT_CNT_SIZE))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.block_counts, cap / RT_BLOCK + 1))) return rc;
+    // the counters and, behind them, the per-chunk lit counts: one memset clears both
+    if ((rc = alloc_into(be->buf_allocs, &Q.counters, (size_t)RT_CNT_SIZE + cap / RT_LIT_CHUNK + 1))) return rc;
+    Q.block_counts = Q.counters + RT_CNT_SIZE;
     if ((rc = alloc_into(be->buf_allocs, &Q.lit_list, cap))) return rc;
+    Q.overflow = be->sticky;
     Q.capacity = capacity;
     be->buf_capacity = capacity;
     be->buf_point_lights = n_point_lights;
@@ -586,8 +584,51 @@ struct Timing {
     }
 };
 
-int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
-                hipStream_t stream, RtStats *stats) {
+}  // namespace
+
+int rt::finish_stream(RtBackend *be, hipStream_t stream) {
+    RT_HIP(hipMemcpyAsync(be->sticky_host, be->sticky, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    RT_HIP(hipGetLastError());
+    if (*be->sticky_host != 0u) {
+        *be->sticky_host = 0u;
+        RT_HIP(hipMemsetAsync(be->sticky, 0, sizeof(uint32_t), stream));
+        return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
+    }
+    return RT_OK;
+}
+
+int rt::ensure_device_fb(RtBackend *be, size_t floats) {
+    if (be->fb_floats >= floats) return RT_OK;
+    if (be->fb) (void)hipFree(be->fb);
+    be->fb = nullptr;
+    be->fb_floats = 0;
+    RT_HIP(hipMalloc((void **)&be->fb, floats * sizeof(float)));
+    be->fb_floats = floats;
+    return RT_OK;
+}
+
+int rt::ensure_pinned(RtBackend *be, size_t floats) {
+    if (be->pinned_floats >= floats) return RT_OK;
+    if (be->pinned) (void)hipHostFree(be->pinned);
+    be->pinned = nullptr;
+    be->pinned_floats = 0;
+    RT_HIP(hipHostMalloc((void **)&be->pinned, floats * sizeof(float), hipHostMallocDefault));
+    be->pinned_floats = floats;
+    return RT_OK;
+}
+
+bool rt::is_pinned_host(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory is unknown to the runtime: that is the answer, not a failure
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
+                     hipStream_t stream, RtStats *stats, bool blocking) {
     if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
     if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
     if (args->antialias_method < RT_AA_NORMAL || args->antialias_method > RT_AA_RANDOM)
@@ -612,6 +653,7 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
 
     RT_HIP(hipSetDevice(be->device));
     if (!stream) stream = be->stream;
+    be->last_stream = stream;
 
     // ---- tile list (cached per partition)
     const uint32_t key[6] = {W, H, tw, th, args->part_index, parts | (args->part0_weight << 24)};
@@ -628,8 +670,7 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
     const uint32_t n_slots = (uint32_t)be->tile_list_host.size();
 
     // ---- batch size
-    uint64_t max_batch = 16ull << 20;
-    if (const char *e = std::getenv("RT_BATCH_SAMPLES")) max_batch = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    const uint64_t max_batch = args->batch_samples ? args->batch_samples : (16ull << 20);
     const uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / tile_samples);
     const uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
     const uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
@@ -667,18 +708,20 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         RT_HIP(hipEventRecord(ev0, stream));
     }
     const bool ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
-    uint32_t xcd_chunk_fixed = 0;
-    if (const char *e = std::getenv("RT_XCD_CHUNK")) xcd_chunk_fixed = (uint32_t)std::max(1, std::atoi(e));
     const int max_bounce = ds->has_mirror ? S.recursion_depth : 0;
     std::vector<uint32_t> host_counters;
-    // fast mode: wave packets for camera and shadow rays (RT_PACKET=0 keeps the per-lane kernels, for comparison)
-    bool use_packets = true;
-    if (const char *e = std::getenv("RT_PACKET")) use_packets = std::atoi(e) != 0;
+    // fast mode: wave packets for camera and shadow rays, unless the caller asks for the per-lane kernels
+    const bool use_packets = (args->flags & RT_RENDER_NO_PACKETS) == 0u;
+    // shadow rays and light sums in one kernel: needs the packet path and a bit per point light
+    const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u;
     // One ray per lane in the packet kernels.  Two per lane (the template's R) halve the steps per
     // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
     constexpr int packet_rays = 1;
     const size_t packet_lds = ((size_t)(std::max(S.stack_depth, 1) + 1) + 6u * 64u * (size_t)packet_rays) * sizeof(int32_t);
+    // a wait per batch: to read the counters for the statistics, or to serve the progress callback
+    const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
+    const bool wait_batches = stats != nullptr || serve_progress;
 
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
@@ -690,14 +733,15 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         B.width = W; B.height = H;
         B.n = n;
         B.compact_fb = parts > 1 ? 1u : 0u;
+        B.fused_shadows = fused ? 1u : 0u;
         B.aa_method = args->antialias_method;
         B.seed = args->seed;
-        rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
-        if (const char *e = std::getenv("RT_PIXEL_BLOCK"))  // 0 = plain row-major order, for comparison
-            if (std::atoi(e) == 0) B.blk_w_log2 = B.blk_h_log2 = 0;
+        if ((args->flags & RT_RENDER_ROW_MAJOR_PIXELS) == 0u) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
+        rt_batch_finish(B);
         const uint32_t n_samples = B.n_pixels * spp;
 
-        RT_HIP(hipMemsetAsync(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t), stream));
+        const uint32_t lit_grid = (n_samples + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
+        RT_HIP(hipMemsetAsync(Q.counters, 0, ((size_t)RT_CNT_SIZE + lit_grid) * sizeof(uint32_t), stream));
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
@@ -712,7 +756,7 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         // chunk of the XCD remap, in 256-sample blocks: 128 (a few tiles) for a whole frame, smaller
         // for a small launch so that every XCD still gets >= 32 chunks -- chunks differ in cost, and
         // with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
-        const uint32_t xcd_chunk = xcd_chunk_fixed ? xcd_chunk_fixed : std::min(128u, std::max(8u, full_grid / 256u));
+        const uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, full_grid / 256u));
         for (int bounce = 0; bounce <= max_bounce; ++bounce) {
             // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
             // the device, so a fixed grid strides over it (and costs little when it is empty).
@@ -731,41 +775,46 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         }
         if (ds->has_lit) {
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            const uint32_t lit_grid = (n_samples + RT_LIT_BLOCK - 1) / RT_LIT_BLOCK;
-            hipLaunchKernelGGL(k_lit_count, dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
             hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
             hipLaunchKernelGGL(k_lit_scatter, dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
             tm.end();
             // the number of lit hits is only known on the device: size the grids for the worst
             // case, surplus blocks return at once
-            if (!S.disable_shadows && ds->n_point_lights > 0) {
+            if (fused) {
                 if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                const dim3 sg(full_grid, ds->n_point_lights);
-                if (ref_order)
-                    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
-                else if (use_packets)
-                    hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
-                else
-                    hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
+                hipLaunchKernelGGL(k_shadow_shade_packet, dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, xcd_chunk);
+                tm.end();
+            } else {
+                if (!S.disable_shadows && ds->n_point_lights > 0) {
+                    if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                    const dim3 sg(full_grid, ds->n_point_lights);
+                    if (ref_order)
+                        hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
+                    else if (use_packets)
+                        hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
+                    else
+                        hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
+                    tm.end();
+                }
+                if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
                 tm.end();
             }
-            if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
-            tm.end();
         }
         }
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(B.n_pixels)), dim3(RT_BLOCK), 0, stream, Q, B, fb_dev);
         tm.end();
 
-        if (stats) {
-            // counters must be read before the next batch clears them
-            const size_t at = host_counters.size();
-            host_counters.resize(at + RT_CNT_SIZE);
-            RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, stream));
+        if (wait_batches) {
+            if (stats) {  // counters must be read before the next batch clears them
+                const size_t at = host_counters.size();
+                host_counters.resize(at + RT_CNT_SIZE);
+                RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, stream));
+            }
             RT_HIP(hipStreamSynchronize(stream));
-            if (args->progress) {  // pixels of the owned tiles that lie inside the image, finished / in all
+            if (serve_progress) {  // pixels of the owned tiles that lie inside the image, finished / in all
                 auto inside = [&](uint32_t from, uint32_t to) {
                     uint64_t px = 0;
                     for (uint32_t k = from; k < to; ++k) {
@@ -792,7 +841,6 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
         RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         stats->render_ms = ms;
         tm.collect(stats);
-        bool overflow = false;
         // camera rays = samples of the owned pixels that lie inside the image
         for (int32_t tile : be->tile_list_host) {
             const uint32_t x0 = ((uint32_t)tile % tiles_x) * tw, y0 = ((uint32_t)tile / tiles_x) * th;
@@ -811,14 +859,10 @@ int render_impl(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args
                 stats->shaded_hits += c[RT_CNT_LIT];
                 if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_LIT] * ds->n_point_lights;
             }
-            overflow = overflow || c[RT_CNT_OVERFLOW] != 0;
         }
-        if (overflow) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
     }
-    return RT_OK;
+    return stats ? rt::finish_stream(be, stream) : RT_OK;
 }
-
-}  // namespace
 
 // ------------------------------------------------------------------ C ABI
 
@@ -835,10 +879,15 @@ extern "C" int rt_backend_create(int device_ordinal, RtBackend **backend_out) {
     RtBackend *be = new RtBackend();
     be->device = device_ordinal;
     hipError_t e = hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&be->sticky, 256);
+    if (e == hipSuccess) e = hipMemset(be->sticky, 0, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&be->sticky_host, 64, hipHostMallocDefault);
     if (e != hipSuccess) {
-        delete be;
-        return rt::set_error(RT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        rt_backend_destroy(be);
+        return rt::set_error(RT_ERR_DEVICE, std::string("backend set-up: ") + hipGetErrorString(e));
     }
+    *be->sticky_host = 0u;
+    be->last_stream = be->stream;
     *backend_out = be;
     return RT_OK;
 }
@@ -847,6 +896,7 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
     if (!be) return;
     (void)hipSetDevice(be->device);
     if (be->stream) (void)hipStreamSynchronize(be->stream);
+    if (be->last_stream && be->last_stream != be->stream) (void)hipStreamSynchronize(be->last_stream);
     for (auto &p : be->deferred) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -855,13 +905,39 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
     if (be->tile_list) (void)hipFree(be->tile_list);
     if (be->tile_where) (void)hipFree(be->tile_where);
     if (be->fb) (void)hipFree(be->fb);
+    if (be->pinned) (void)hipHostFree(be->pinned);
+    if (be->sticky) (void)hipFree(be->sticky);
+    if (be->sticky_host) (void)hipHostFree(be->sticky_host);
     if (be->stream) (void)hipStreamDestroy(be->stream);
     delete be;
 }
 
+extern "C" int rt_backend_sync(RtBackend *be) {
+    if (!be) return rt::set_error(RT_ERR_INVALID, "null argument");
+    RT_HIP(hipSetDevice(be->device));
+    return rt::finish_stream(be, be->last_stream ? be->last_stream : be->stream);
+}
+
+extern "C" int rt_host_alloc(size_t bytes, void **ptr_out) {
+    if (!ptr_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+    *ptr_out = nullptr;
+    RT_HIP(hipHostMalloc(ptr_out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+    return RT_OK;
+}
+
+extern "C" void rt_host_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
 extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScene **out) {
+    return rt_scene_upload_with(be, scene, nullptr, out);
+}
+
+extern "C" int rt_scene_upload_with(RtBackend *be, const RtScene *scene, const RtUploadOptions *options, RtDeviceScene **out) {
     if (!be || !scene || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
     *out = nullptr;
+    const uint32_t upload_flags = options ? options->flags : 0u;
+    if (upload_flags & ~(uint32_t)RT_UPLOAD_REFERENCE_MESH_TREES) return rt::set_error(RT_ERR_INVALID, "unknown upload flag");
     bool uses_ggx = false;
     for (uint32_t s = 0; s < scene->n_shapes; ++s) {
         const int32_t sh = scene->shapes[s].shader;
@@ -870,7 +946,7 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
     if (uses_ggx && scene->recursion_depth > RT_TREE_MAX_DEPTH)
         return rt::set_error(RT_ERR_UNSUPPORTED, "GGXMirror with a recursion depth above " + std::to_string(RT_TREE_MAX_DEPTH));
     rt::FlatScene flat;
-    const std::string err = rt::flatten_scene(*scene, flat);
+    const std::string err = rt::flatten_scene(*scene, flat, (upload_flags & RT_UPLOAD_REFERENCE_MESH_TREES) != 0u);
     if (!err.empty()) return rt::set_error(RT_ERR_INVALID, err);
     RT_HIP(hipSetDevice(be->device));
 
@@ -962,23 +1038,21 @@ extern "C" uint32_t rt_scene_point_light_count(const RtDeviceScene *ds) { return
 
 extern "C" int rt_render_device(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_dev,
                                 const RtRayIds *ids_dev, void *hip_stream, RtStats *stats_out) {
-    return render_impl(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, stats_out);
+    return rt::render_frame(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, stats_out, false);
 }
 
-namespace {
-
-// Grows the backend's scratch framebuffer to at least `floats`.
-int ensure_scratch_fb(RtBackend *be, size_t floats) {
-    if (be->fb_floats >= floats) return RT_OK;
-    if (be->fb) (void)hipFree(be->fb);
-    be->fb = nullptr;
-    be->fb_floats = 0;
-    RT_HIP(hipMalloc((void **)&be->fb, floats * sizeof(float)));
-    be->fb_floats = floats;
+extern "C" int rt_render_async(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_pinned) {
+    if (!be || !ds || !args || !fb_rgb_pinned) return rt::set_error(RT_ERR_INVALID, "null argument");
+    if (args->part_count > 1) return rt::set_error(RT_ERR_INVALID, "rt_render_async renders whole frames (part_count <= 1)");
+    RT_HIP(hipSetDevice(be->device));
+    if (!rt::is_pinned_host(fb_rgb_pinned))
+        return rt::set_error(RT_ERR_INVALID, "rt_render_async needs page-locked host memory (rt_host_alloc)");
+    const size_t fb_floats = (size_t)ds->width * ds->height * 3;
+    if (int grown = rt::ensure_device_fb(be, fb_floats)) return grown;
+    if (int rc = rt::render_frame(be, ds, args, be->fb, nullptr, be->stream, nullptr, false)) return rc;
+    RT_HIP(hipMemcpyAsync(fb_rgb_pinned, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream));
     return RT_OK;
 }
-
-}  // namespace
 
 extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb,
                          const RtRayIds *ids_host, RtStats *stats_out) {
@@ -993,8 +1067,7 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
     const uint32_t tiles_x = ((uint32_t)W + tw - 1) / tw, tiles_y = ((uint32_t)H + th - 1) / th;
     // a partitioned render lands tile-major (edge tiles padded), so size for whole tiles
     const size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
-    if (int grown = ensure_scratch_fb(be, dev_floats)) return grown;
-    RT_HIP(hipMemsetAsync(be->fb, 0, fb_floats * sizeof(float), be->stream));
+    if (int grown = rt::ensure_device_fb(be, dev_floats)) return grown;
 
     // device mirrors of the requested id arrays
     std::vector<void *> tmp;
@@ -1029,137 +1102,54 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
             copies.push_back({w.host, (int32_t *)p, w.count});
         }
     }
-    const RtRenderArgs &a = *args;
-    int rc;
-    RtStats local_stats;
-    rc = render_impl(be, ds, &a, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out ? stats_out : &local_stats);
+    // The kernels are only enqueued here (statistics and a progress callback excepted, which make
+    // render_frame wait); the copy of the frame follows on the same stream, and ONE wait ends the call.
+    int rc = rt::render_frame(be, ds, args, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out, true);
     if (rc) {
         cleanup();
         return rc;
     }
-    if (parts > 1) {
-        // compact tile-major -> full layout on the host, owned pixels only
-        std::vector<float> compact(be->tile_list_host.size() * tw * th * 3);
-        if (!compact.empty()) {
-            hipError_t e = hipMemcpy(compact.data(), be->fb, compact.size() * sizeof(float), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) {
-                cleanup();
-                return rt::set_error(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
-            }
+    auto fail = [&](hipError_t e, const char *what) {
+        cleanup();
+        return rt::set_error(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    // what to bring over: the frame, or the owned tiles of a part (tile-major, scattered below)
+    const size_t copy_floats = parts > 1 ? be->tile_list_host.size() * tw * th * 3 : fb_floats;
+    const bool direct = parts <= 1 && rt::is_pinned_host(fb_rgb);  // the device can write the caller's memory itself
+    float *landing = fb_rgb;
+    if (!direct) {
+        if (int grown = rt::ensure_pinned(be, std::max<size_t>(copy_floats, 1))) {
+            cleanup();
+            return grown;
         }
+        landing = be->pinned;
+    }
+    if (copy_floats) {
+        hipError_t e = hipMemcpyAsync(landing, be->fb, copy_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream);
+        if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
+    }
+    for (auto &c : copies) {  // pageable destinations: the runtime stages these itself
+        hipError_t e = hipMemcpyAsync(c.host, c.dev, c.count * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream);
+        if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
+    }
+    if ((rc = rt::finish_stream(be, be->stream))) {
+        cleanup();
+        return rc;
+    }
+    if (parts > 1) {
+        // compact tile-major -> full layout, owned pixels only
         for (size_t s = 0; s < be->tile_list_host.size(); ++s) {
             const uint32_t tile = (uint32_t)be->tile_list_host[s];
-            for (uint32_t r = 0; r < tw * th; ++r) {
-                const uint32_t i = (tile % tiles_x) * tw + r % tw, j = (tile / tiles_x) * th + r / tw;
-                if (i >= W || j >= H) continue;
-                const size_t src = (s * tw * th + r) * 3;
-                std::memcpy(fb_rgb + (i + (size_t)j * W) * 3, compact.data() + src, 3 * sizeof(float));
-            }
+            const uint32_t x0 = (tile % tiles_x) * tw, y0 = (tile / tiles_x) * th;
+            const uint32_t w_in = std::min<uint32_t>(tw, (uint32_t)W - x0), h_in = std::min<uint32_t>(th, (uint32_t)H - y0);
+            for (uint32_t y = 0; y < h_in; ++y)
+                std::memcpy(fb_rgb + ((size_t)x0 + (size_t)(y0 + y) * W) * 3, landing + (s * tw * th + (size_t)y * tw) * 3,
+                            (size_t)w_in * 3 * sizeof(float));
         }
-    } else {
-        hipError_t e = hipMemcpy(fb_rgb, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            cleanup();
-            return rt::set_error(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
-        }
-    }
-    for (auto &c : copies) {
-        hipError_t e = hipMemcpy(c.host, c.dev, c.count * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            cleanup();
-            return rt::set_error(RT_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
-        }
+    } else if (!direct) {
+        std::memcpy(fb_rgb, landing, fb_floats * sizeof(float));
     }
     cleanup();
-    return RT_OK;
-}
-
-extern "C" int rt_render_multi(RtBackend *const *bes, RtDeviceScene *const *dss, uint32_t n, const RtRenderArgs *args,
-                               float *fb_rgb, RtStats *stats_out) {
-    if (!bes || !dss || !args || !fb_rgb || n == 0) return rt::set_error(RT_ERR_INVALID, "null argument");
-    for (uint32_t k = 0; k < n; ++k) {
-        if (!bes[k] || !dss[k]) return rt::set_error(RT_ERR_INVALID, "null backend or scene");
-        if (dss[k]->width != dss[0]->width || dss[k]->height != dss[0]->height)
-            return rt::set_error(RT_ERR_INVALID, "the scenes of the parts differ in size");
-        for (uint32_t j = 0; j < k; ++j)
-            if (bes[j] == bes[k]) return rt::set_error(RT_ERR_INVALID, "every part needs a backend of its own");
-    }
-    if (n == 1) {
-        RtRenderArgs a = *args;
-        a.part_index = 0;
-        a.part_count = 1;
-        return rt_render(bes[0], dss[0], &a, fb_rgb, nullptr, stats_out);
-    }
-    const auto t_begin = std::chrono::steady_clock::now();
-    const uint32_t W = dss[0]->width, H = dss[0]->height;
-    RtRenderArgs a0 = *args;
-    a0.part_index = 0;
-    a0.part_count = n;
-    a0.progress = nullptr;
-    uint32_t stride = 0;
-    int rc = rt_partition_info(W, H, &a0, nullptr, nullptr, &stride);
-    if (rc) return rc;
-    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    const size_t block_floats = (size_t)stride * tw * th * 3;
-
-    // one host thread per part: each renders into its backend's scratch buffer and waits for it
-    std::vector<int> part_rc(n, RT_OK);
-    std::vector<std::string> part_msg(n);
-    std::vector<RtStats> part_stats(n);
-    std::vector<std::thread> workers;
-    for (uint32_t k = 0; k < n; ++k)
-        workers.emplace_back([&, k]() {
-            RtRenderArgs a = a0;
-            a.part_index = k;
-            int r = hipSetDevice(bes[k]->device) == hipSuccess ? RT_OK : rt::set_error(RT_ERR_DEVICE, "hipSetDevice failed");
-            if (!r) r = ensure_scratch_fb(bes[k], block_floats);
-            if (!r) r = render_impl(bes[k], dss[k], &a, bes[k]->fb, nullptr, bes[k]->stream, &part_stats[k]);
-            part_rc[k] = r;
-            if (r) part_msg[k] = rt::last_error_slot();  // the slot is per thread
-        });
-    for (auto &w : workers) w.join();
-    for (uint32_t k = 0; k < n; ++k)
-        if (part_rc[k]) return rt::set_error(part_rc[k], "part " + std::to_string(k) + ": " + part_msg[k]);
-
-    // the parts' tiles, end to end on the first backend's device, then the image layout
-    RtBackend *root = bes[0];
-    RT_HIP(hipSetDevice(root->device));
-    float *gathered = nullptr, *frame = nullptr;
-    auto release = [&]() {
-        if (gathered) (void)hipFree(gathered);
-        if (frame) (void)hipFree(frame);
-    };
-    const size_t fb_floats = (size_t)W * H * 3;
-    if (hipMalloc((void **)&gathered, (size_t)n * block_floats * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&frame, fb_floats * sizeof(float)) != hipSuccess) {
-        release();
-        return rt::set_error(RT_ERR_DEVICE, "hipMalloc of the gather buffers failed");
-    }
-    for (uint32_t k = 0; k < n; ++k)
-        if (hipMemcpy(gathered + (size_t)k * block_floats, bes[k]->fb, block_floats * sizeof(float), hipMemcpyDefault) != hipSuccess) {
-            release();
-            return rt::set_error(RT_ERR_DEVICE, "copy of part " + std::to_string(k) + " to the first device failed");
-        }
-    rc = rt_untile_device(root, W, H, &a0, gathered, frame, root->stream);
-    if (!rc && (hipStreamSynchronize(root->stream) != hipSuccess ||
-                hipMemcpy(fb_rgb, frame, fb_floats * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
-        rc = rt::set_error(RT_ERR_DEVICE, "un-tile or copy to the host failed");
-    release();
-    if (rc) return rc;
-    if (stats_out) {
-        std::memset(stats_out, 0, sizeof(*stats_out));
-        for (const RtStats &p : part_stats) {
-            stats_out->primary_rays += p.primary_rays;
-            stats_out->secondary_rays += p.secondary_rays;
-            stats_out->shadow_rays += p.shadow_rays;
-            stats_out->shaded_hits += p.shaded_hits;
-            for (int c = 0; c < RT_K_COUNT; ++c) {
-                stats_out->kernel_ms[c] += p.kernel_ms[c];
-                stats_out->kernel_launches[c] += p.kernel_launches[c];
-            }
-        }
-        stats_out->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    }
     return RT_OK;
 }
 

@@ -1,0 +1,89 @@
+// rt_backend_internal.h -- what the two host-side translation units of librt_hip.so share:
+// the backend and device-scene objects behind the opaque handles of include/rt_hip.h, and the
+// few internal entry points the multi-device code (rt_multi.cpp) builds on.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_error.h"
+#include "rt_pipeline.h"
+
+#define RT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return rt::set_error(RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct RtEventPair {
+    hipEvent_t a, b;
+    int klass;
+};
+
+struct RtBackend {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;  // stream of the most recent enqueue; rt_backend_sync waits for it
+    // event pairs of frames enqueued with RtRenderArgs::timed_classes, until rt_collect_timings
+    std::vector<RtEventPair> deferred;
+    hipStream_t deferred_stream = nullptr;
+    // batch buffers, grown on demand
+    RtBuffers buf{};
+    std::vector<void *> buf_allocs;
+    uint32_t buf_capacity = 0;
+    uint32_t buf_point_lights = 0;
+    // "a traversal stack overflowed" (RtBuffers::overflow): a device word that kernels only ever set,
+    // and the page-locked host word it is copied to when the host looks
+    uint32_t *sticky = nullptr;
+    uint32_t *sticky_host = nullptr;
+    // tile list of the last partition
+    int32_t *tile_list = nullptr;
+    std::vector<int32_t> tile_list_host;
+    uint32_t tile_key[6] = {0, 0, 0, 0, 0, 0};
+    // tile -> position lookup of rt_untile_device
+    uint32_t *tile_where = nullptr;
+    uint32_t untile_key[5] = {0, 0, 0, 0, 0};
+    // device framebuffer and page-locked staging buffer of rt_render / rt_render_async
+    float *fb = nullptr;
+    size_t fb_floats = 0;
+    float *pinned = nullptr;
+    size_t pinned_floats = 0;
+};
+
+struct RtDeviceScene {
+    RtBackend *backend = nullptr;  // identity check only; may already be destroyed when the scene is freed
+    int device = 0;
+    RtSceneView view{};       // reference-order mode: the reference's scene-level tree
+    RtSceneView view_fast{};  // fast mode: the same arrays, entered through the fast mode's scene-level tree
+    std::vector<void *> allocs;
+    uint32_t width = 0, height = 0;
+    uint32_t n_point_lights = 0;
+    bool has_mirror = false;
+    bool has_lit = false;
+    bool has_ggx = false;  // a shape uses GGXMirror: frames go through the ray-tree kernel
+};
+
+namespace rt {
+
+// Enqueues one frame (or one part of it) on `stream`.  `stats` non-null: every kernel class is timed,
+// the call waits for the frame and checks the overflow word.  `blocking`: the caller is going to wait
+// for the frame anyway (and calls finish_stream itself), so the progress callback may be served,
+// which takes a wait per batch.
+int render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
+                 hipStream_t stream, RtStats *stats, bool blocking);
+
+// Waits for `stream` and turns a set overflow word into an error (clearing it).
+int finish_stream(RtBackend *be, hipStream_t stream);
+
+// Grow-only device framebuffer / page-locked staging buffer of a backend.
+int ensure_device_fb(RtBackend *be, size_t floats);
+int ensure_pinned(RtBackend *be, size_t floats);
+
+// True when `p` is host memory the device can write directly (hipHostMalloc / hipHostRegister).
+bool is_pinned_host(const void *p);
+
+}  // namespace rt

@@ -125,7 +125,7 @@ RT_HD D3 transform_point(const double *m, const D3 &p) {
     D3 r = transform_vector(m, p);
     r = D3{r.x + m[3], r.y + m[7], r.z + m[11]};
     const double n = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
-    if (n != 0.0) r = r / n;
+    if (n != 0.0 && n != 1.0) r = r / n;  // x / 1.0 is x, bit for bit: an affine matrix costs no division
     return r;
 }
 

@@ -121,6 +121,30 @@ inline uint32_t rt_tile_map_owner(const RtTileMap &m, uint32_t tx, uint32_t ty) 
     return 1u + (lane - part0_lanes_below) % (m.parts - 1u);
 }
 
+// Division of a dividend below 2^31 by a divisor fixed on the host, as one 32 x 32 -> 64 bit
+// multiplication and a shift.  The index arithmetic of a sample (sample -> pixel -> tile) divides
+// by five such numbers; a hardware integer division costs a wave about 25 instructions each, in
+// kernels whose remaining work per sample is a few hundred.
+// With l = ceil(log2 d) and m = floor(2^(31 + l) / d) + 1 (which fits 32 bits), floor(n * m / 2^(31 + l))
+// = floor(n / d) for every n < 2^31 (Granlund & Montgomery, "Division by invariant integers using
+// multiplication", PLDI'94, theorem 4.2 with N = 31).
+struct RtDiv {
+    uint32_t d, m, sh;
+};
+
+inline RtDiv rt_div_make(uint32_t d) {
+    RtDiv v;
+    v.d = d < 1 ? 1 : d;
+    uint32_t l = 0;
+    while ((1ull << l) < v.d) ++l;
+    v.sh = 31 + l;
+    v.m = (uint32_t)((1ull << v.sh) / v.d + 1ull);
+    return v;
+}
+
+RT_TYPES_INL uint32_t rt_div(uint32_t n, const RtDiv &v) { return (uint32_t)(((uint64_t)n * v.m) >> v.sh); }
+RT_TYPES_INL uint32_t rt_mod(uint32_t n, const RtDiv &v) { return n - rt_div(n, v) * v.d; }
+
 // Pixel block of the in-tile order (RtBatch::blk_*_log2): the power-of-two block, as square as
 // possible (wider than high if not), that holds about 64 samples and divides the tile.
 inline void rt_pixel_block(uint32_t tile_w, uint32_t tile_h, uint32_t samples_per_pixel, uint32_t &w_log2, uint32_t &h_log2) {

@@ -59,6 +59,7 @@ struct RtBuffers {
     double *l_d[3];  // direction of the ray that hit (un-normalised)
     int32_t *l_shape;
     int32_t *l_tri;
+    uint32_t *l_self;  // bit k: the hit's own primitive blocks point light k (f64 test in the shade stage)
     // [point light slot * capacity + sample]: blocker, -1 = light visible
     int32_t *occ_shape;
     int32_t *occ_tri;
@@ -67,15 +68,20 @@ struct RtBuffers {
     float *color;
     // device counters, see RT_CNT_*
     uint32_t *counters;
-    uint32_t *block_counts;  // per-256-sample-block lit counts, then their exclusive prefix sums
+    uint32_t *overflow;      // set to 1 by a traversal whose stack would have overflowed (must stay 0); never
+                             // cleared by the device, so that it survives until the host looks
+    uint32_t *block_counts;  // lit hits per chunk of RT_LIT_CHUNK samples (added up by the shade stage), then
+                             // their exclusive prefix sums; lies behind the counters and is cleared with them
     uint32_t *lit_list;      // samples that have a lit hit, ascending
     uint32_t capacity;       // samples a batch can hold
 };
 
+#define RT_LIT_CHUNK 1024u
+
 enum {
     RT_CNT_RAYS0 = 0,      // [1 .. 31]: rays in the queue of bounce b (b >= 1)
     RT_CNT_LIT = 32,       // lit hits of the batch
-    RT_CNT_OVERFLOW = 33,  // traversal-stack overflows (must stay 0)
+    RT_CNT_UNUSED = 33,
     // ray-tree path (rt_tree.h): 64-bit counts, two dwords each
     RT_CNT_TREE_SECONDARY = 34,
     RT_CNT_TREE_SHADOW = 36,
@@ -93,6 +99,7 @@ struct RtBatch {
     uint32_t width, height;
     uint32_t n;           // sqrt_rays_per_pixel
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
+    uint32_t fused_shadows;  // 1: shadow rays and light sums run in one kernel that reads l_self, not the occ_* arrays
     int32_t aa_method;    // RT_AA_*
     uint64_t seed;        // key of the sample-offset generator
     // Order of the pixels inside a tile: in blocks of (1 << blk_w_log2) x (1 << blk_h_log2) pixels,
@@ -101,32 +108,47 @@ struct RtBatch {
     // image instead of a strip one pixel high, and the nodes their rays visit overlap more.
     // 0 / 0 = plain row-major order.
     uint32_t blk_w_log2, blk_h_log2;
+    // divisors of the index arithmetic below, filled by rt_batch_finish
+    RtDiv div_tile_px;      // tile_w * tile_h
+    RtDiv div_blocks_row;   // tile_w >> blk_w_log2
+    RtDiv div_tiles_x;
+    RtDiv div_spp;          // n * n
+    RtDiv div_n;
 };
+
+// Call once all other fields are set.
+inline void rt_batch_finish(RtBatch &B) {
+    B.div_tile_px = rt_div_make(B.tile_w * B.tile_h);
+    B.div_blocks_row = rt_div_make(B.tile_w >> B.blk_w_log2);
+    B.div_tiles_x = rt_div_make(B.tiles_x);
+    B.div_spp = rt_div_make(B.n * B.n);
+    B.div_n = rt_div_make(B.n);
+}
 
 struct RtIdOut {  // RtRayIds, device pointers (any may be null)
     int32_t *primary_shape, *primary_tri, *final_shape, *final_tri, *bounces, *shadow_shape, *shadow_tri;
 };
 
 RT_HD bool batch_pixel(const RtBatch &B, uint32_t lp, uint32_t &i, uint32_t &j) {
-    const uint32_t tp = B.tile_w * B.tile_h;
-    const uint32_t slot = B.slot0 + lp / tp, r = lp % tp;
-    const uint32_t tile = (uint32_t)B.tile_list[slot];
+    const uint32_t in_batch = rt_div(lp, B.div_tile_px), r = lp - in_batch * B.div_tile_px.d;
+    const uint32_t tile = (uint32_t)B.tile_list[B.slot0 + in_batch];
     const uint32_t bshift = B.blk_w_log2 + B.blk_h_log2;
     const uint32_t blk = r >> bshift, in_blk = r & ((1u << bshift) - 1u);
-    const uint32_t blocks_per_row = B.tile_w >> B.blk_w_log2;
-    const uint32_t x = ((blk % blocks_per_row) << B.blk_w_log2) + (in_blk & ((1u << B.blk_w_log2) - 1u));
-    const uint32_t y = ((blk / blocks_per_row) << B.blk_h_log2) + (in_blk >> B.blk_w_log2);
-    i = (tile % B.tiles_x) * B.tile_w + x;
-    j = (tile / B.tiles_x) * B.tile_h + y;
+    const uint32_t blk_y = rt_div(blk, B.div_blocks_row), blk_x = blk - blk_y * B.div_blocks_row.d;
+    const uint32_t x = (blk_x << B.blk_w_log2) + (in_blk & ((1u << B.blk_w_log2) - 1u));
+    const uint32_t y = (blk_y << B.blk_h_log2) + (in_blk >> B.blk_w_log2);
+    const uint32_t tile_y = rt_div(tile, B.div_tiles_x), tile_x = tile - tile_y * B.div_tiles_x.d;
+    i = tile_x * B.tile_w + x;
+    j = tile_y * B.tile_h + y;
     return i < B.width && j < B.height;
 }
 
 // Global sample index of RtRayIds for a local sample.
 RT_HD size_t global_sample(const RtBatch &B, uint32_t ls) {
-    const uint32_t spp = B.n * B.n;
+    const uint32_t lp = rt_div(ls, B.div_spp);
     uint32_t i, j;
-    batch_pixel(B, ls / spp, i, j);
-    return ((size_t)i + (size_t)j * B.width) * spp + ls % spp;
+    batch_pixel(B, lp, i, j);
+    return ((size_t)i + (size_t)j * B.width) * B.div_spp.d + (ls - lp * B.div_spp.d);
 }
 
 RT_HD int32_t tri_file_index(const RtSceneView &S, int32_t gtri) {
@@ -136,12 +158,14 @@ RT_HD int32_t tri_file_index(const RtSceneView &S, int32_t gtri) {
 // Camera ray of a local sample (render.rs:64-68); false for the padding pixels of
 // a tile that sticks out of the image.
 RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls, D3 &o, D3 &d) {
-    const uint32_t spp = B.n * B.n;
+    const uint32_t spp = B.div_spp.d;
+    const uint32_t lp = rt_div(ls, B.div_spp);
     uint32_t i, j;
-    if (!batch_pixel(B, ls / spp, i, j)) return false;
-    const uint32_t k = ls % spp;
+    if (!batch_pixel(B, lp, i, j)) return false;
+    const uint32_t k = ls - lp * spp;
+    const uint32_t p = rt_div(k, B.div_n);
     double di, dj;
-    sample_offsets(B.aa_method, B.seed, ((uint64_t)i + (uint64_t)j * B.width) * spp + k, k / B.n, k % B.n, B.n, di, dj);
+    sample_offsets(B.aa_method, B.seed, ((uint64_t)i + (uint64_t)j * B.width) * spp + k, p, k - p * B.n, B.n, di, dj);
     camera_ray(S.camera, i, j, di, dj, o, d);
     return true;
 }
@@ -209,7 +233,7 @@ RT_HD void trace_closest_body(const RtSceneView &S, const RtBuffers &Q, const Rt
         org_tri = r.org_tri;
     }
     if (!traverse<Stack, ORDERED, false, EXACT>(S, ray, closest_tmin(bounce), hit, org_shape, org_tri, stk, S.stack_depth))
-        Q.counters[RT_CNT_OVERFLOW] = 1;
+        *Q.overflow = 1;
     closest_store(Q, idx, hit.t, hit.shape, hit.tri);
 }
 
@@ -227,12 +251,12 @@ RT_HD void trace_closest_fast_body(const RtSceneView &S, const RtBuffers &Q, con
     const float tmin = closest_tmin(bounce);
     while (fast_step<Stack, false>(S, st, stk, tmin, S.stack_depth, overflow)) {
     }
-    if (overflow) Q.counters[RT_CNT_OVERFLOW] = 1;
+    if (overflow) *Q.overflow = 1;
     closest_store(Q, idx, st.t, st.shape, st.tri);
 }
 
 // ---- shade
-enum { RT_ACT_NONE = 0, RT_ACT_MIRROR = 1 };
+enum { RT_ACT_NONE = 0, RT_ACT_MIRROR = 1, RT_ACT_LIT = 2 };
 
 struct MirrorTmp {
     D3 p, d;  // origin and direction of the reflected ray
@@ -291,12 +315,17 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         RT_STREAM_ST(Q.l_d[0][sample], d.x); RT_STREAM_ST(Q.l_d[1][sample], d.y); RT_STREAM_ST(Q.l_d[2][sample], d.z);
         RT_STREAM_ST(Q.l_shape[sample], shape);
         RT_STREAM_ST(Q.l_tri[sample], gtri);
+        uint32_t self_mask = 0;
         if (!S.disable_shadows) {
             // Hit::to_light (hit_struct.rs:29-39) against the primitive the shadow ray starts on
             for (int ls = 0; ls < S.n_point_lights; ++ls) {
                 const D3 dir = d3(S.lights[S.point_lights[ls]].position) - p;  // Ray::atob, ray.rs:15-20
                 double st = 0.0;
                 const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, st);
+                if (B.fused_shadows) {
+                    self_mask |= self ? 1u << (ls & 31) : 0u;
+                    continue;
+                }
                 const size_t k = (size_t)ls * Q.capacity + (size_t)sample;
                 RT_STREAM_ST(Q.occ_shape[k], self ? shape : -1);
                 if (self) {  // rare; the other two arrays are only read where occ_shape says "blocked"
@@ -305,7 +334,8 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
                 }
             }
         }
-        return RT_ACT_NONE;
+        if (B.fused_shadows) RT_STREAM_ST(Q.l_self[sample], self_mask);
+        return RT_ACT_LIT;
     }
     case RT_SHADER_PERFECT_MIRROR: {  // perfect_mirror.rs:9-32
         if (bounce >= S.recursion_depth) {
@@ -403,7 +433,7 @@ RT_HD void trace_shadow_body(const RtSceneView &S, const RtBuffers &Q, uint32_t 
     }
     if (!traverse<Stack, ORDERED, ANYHIT, EXACT>(S, ray, (float)RT_VERY_SMALL_NUMBER, hit, org_shape, org_tri, stk,
                                                  S.stack_depth))
-        Q.counters[RT_CNT_OVERFLOW] = 1;
+        *Q.overflow = 1;
     shadow_store(Q, light_slot, sample, hit.shape, hit.tri);
 }
 
@@ -419,12 +449,33 @@ RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint
     bool overflow = false;
     while (fast_step<Stack, true>(S, st, stk, (float)RT_VERY_SMALL_NUMBER, S.stack_depth, overflow)) {
     }
-    if (overflow) Q.counters[RT_CNT_OVERFLOW] = 1;
+    if (overflow) *Q.overflow = 1;
     shadow_store(Q, light_slot, sample, st.shape, st.tri);
 }
 
 // ---- accumulate: lambertian.rs:17-36 / blinn_phong.rs:23-47.  Returns true if the
 // sample had a lit hit (callers normally only pass such samples).
+// The same sum for a lit sample whose shadow rays were traced by the caller: bit k of `blocked` = point
+// light k (in scene order among the point lights) is hidden.
+RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, uint32_t blocked) {
+    const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+    const D3 n = D3{RT_STREAM_LD(Q.l_n[0][sample]), RT_STREAM_LD(Q.l_n[1][sample]), RT_STREAM_LD(Q.l_n[2][sample])};
+    const D3 d = D3{RT_STREAM_LD(Q.l_d[0][sample]), RT_STREAM_LD(Q.l_d[1][sample]), RT_STREAM_LD(Q.l_d[2][sample])};
+    const RtShader &sh = S.shaders[S.shapes[shape].shader];
+    ColorF color = {0.0f, 0.0f, 0.0f};
+    int slot = 0;
+    for (int li = 0; li < S.n_lights; ++li) {
+        const RtLight &light = S.lights[li];
+        if (light.type == RT_LIGHT_AMBIENT) {  // ambient.rs:25-27
+            add_light(sh, light, n, n, d, color);
+            continue;
+        }
+        if (((blocked >> (slot & 31)) & 1u) == 0u) add_light(sh, light, n, d3(light.position) - p, d, color);
+        ++slot;
+    }
+    write_color(Q, (int32_t)sample, color.r, color.g, color.b);
+}
+
 RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids,
                            uint32_t sample) {
     const int32_t shape = Q.l_shape[sample];
@@ -475,7 +526,7 @@ RT_HD void resolve_body(const RtBuffers &Q, const RtBatch &B, uint32_t lp, float
     float *px;
     if (B.compact_fb) {
         const uint32_t tp = B.tile_w * B.tile_h;  // tiles are stored row-major whatever the order they were worked in
-        px = fb + ((size_t)(B.slot0 + lp / tp) * tp + (size_t)(j % B.tile_h) * B.tile_w + i % B.tile_w) * 3;
+        px = fb + ((size_t)(B.slot0 + rt_div(lp, B.div_tile_px)) * tp + (size_t)(j % B.tile_h) * B.tile_w + i % B.tile_w) * 3;
     } else {
         px = fb + ((size_t)i + (size_t)j * B.width) * 3;
     }

@@ -236,7 +236,7 @@ RT_HD void tree_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B,
     int32_t ps, pt;
     bool ok = true;
     const ColorF c = tree_sample<Stack, FAST>(S, stk, o, d, (uint64_t)gs, B.seed, ps, pt, counts, ok);
-    if (!ok) Q.counters[RT_CNT_OVERFLOW] = 1;
+    if (!ok) *Q.overflow = 1;
     write_color(Q, (int32_t)ls, c.r, c.g, c.b);
     // of the per-sample ids only the camera ray's hit is defined for a tree
     if (ids.primary_shape) ids.primary_shape[gs] = ps;

@@ -64,8 +64,11 @@ struct HostScene {
     bool has_mirror = false, has_lit = false, has_ggx = false;
 };
 
+// what rt_scene_upload_with's options select on the device: set by hostsim_upload_options
+uint32_t g_upload_flags = 0;
+
 std::string make_view(const RtScene &scene, HostScene &hs) {
-    std::string err = rt::flatten_scene(scene, hs.flat);
+    std::string err = rt::flatten_scene(scene, hs.flat, (g_upload_flags & RT_UPLOAD_REFERENCE_MESH_TREES) != 0);
     if (!err.empty()) return err;
     for (uint32_t i = 0; i < scene.n_lights; ++i)
         if (scene.lights[i].type == RT_LIGHT_POINT) hs.point_lights.push_back((int32_t)i);
@@ -152,7 +155,10 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     Q.occ_tri = grab<int32_t>(pool, (size_t)cap * std::max(npl, 1u));
     Q.occ_t = grab<float>(pool, (size_t)cap * std::max(npl, 1u));
     Q.color = grab<float>(pool, (size_t)cap * 3);
+    Q.l_self = grab<uint32_t>(pool, cap);
     Q.counters = grab<uint32_t>(pool, RT_CNT_SIZE);
+    uint32_t overflow_word = 0;
+    Q.overflow = &overflow_word;
     Q.block_counts = grab<uint32_t>(pool, 1);
     Q.lit_list = grab<uint32_t>(pool, 1);
     std::memset(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t));
@@ -168,7 +174,8 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     B.compact_fb = 0;  // the simulator always writes the full-image layout
     B.aa_method = args.antialias_method;
     B.seed = args.seed;
-    rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
+    if (!(args.flags & RT_RENDER_ROW_MAJOR_PIXELS)) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
+    rt_batch_finish(B);
 
     RtIdOut io{};
     if (ids) {
@@ -212,7 +219,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
             stats->secondary_rays = secondary;
             stats->shadow_rays = shadow;
             stats->shaded_hits = shaded;
-            stats->kernel_launches[0] = Q.counters[RT_CNT_OVERFLOW];
+            stats->kernel_launches[0] = overflow_word;
         }
         return;
     }
@@ -278,7 +285,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
         for (int b = 1; b <= max_bounce; ++b) stats->secondary_rays += Q.counters[RT_CNT_RAYS0 + b];
         stats->shaded_hits = (uint64_t)lit;
         if (!S.disable_shadows) stats->shadow_rays = (uint64_t)lit * npl;
-        stats->kernel_launches[0] = Q.counters[RT_CNT_OVERFLOW];  // reused: nonzero = stack overflow
+        stats->kernel_launches[0] = overflow_word;  // reused: nonzero = stack overflow
     }
 }
 
@@ -300,6 +307,8 @@ extern "C" void hostsim_tally(unsigned long long out[3]) {
     tally_flush();
     for (int k = 0; k < 3; ++k) { out[k] = g_total[k]; g_total[k] = 0; }
 }
+
+extern "C" void hostsim_upload_options(uint32_t upload_flags) { g_upload_flags = upload_flags; }
 
 extern "C" int hostsim_render(const RtScene *scene, const RtRenderArgs *args, float *fb, const RtRayIds *ids,
                               RtStats *stats) {
@@ -419,7 +428,8 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
     B.tile_list = tile_list.data();
     B.n_pixels = (uint32_t)tile_list.size() * tw * th;
     B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x; B.width = W; B.height = H; B.n = n;
-    if (!std::getenv("RT_PIXEL_BLOCK") || std::atoi(std::getenv("RT_PIXEL_BLOCK")) != 0) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
+    if (!(args->flags & RT_RENDER_ROW_MAJOR_PIXELS)) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
+    rt_batch_finish(B);
     const long n_samples = (long)B.n_pixels * spp;
     // rays: camera rays, or shadow rays from the camera rays' hit points
     struct R { D3 o, d; float tmin, tmax; int32_t os, ot; bool anyhit; uint32_t i, j; };

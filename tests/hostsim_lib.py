@@ -33,12 +33,16 @@ def lib():
         L.hostsim_bvh_dump.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int32)]
         L.hostsim_bvh_dump.restype = C.c_int64
+        L.hostsim_upload_options.argtypes = [C.c_uint32]
+        L.hostsim_upload_options.restype = None
         _lib = L
     return _lib
 
 
-def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), part=(0, 1), aa=0, seed=0, part0_weight=0):
+def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), part=(0, 1), aa=0, seed=0, part0_weight=0,
+           upload_flags=0, flags=0):
     W, H = scene.image_width, scene.image_height
+    lib().hostsim_upload_options(int(upload_flags))
     a = rt.RtRenderArgs()
     a.sqrt_rays_per_pixel = sqrt_rpp
     a.mode = mode
@@ -46,6 +50,7 @@ def render(scene, sqrt_rpp, mode=rt.RT_MODE_FAST, want_ids=True, tile=(0, 0), pa
     a.part_index, a.part_count = part
     a.part0_weight = part0_weight
     a.antialias_method, a.seed = int(aa), int(seed)
+    a.flags = int(flags)
     fb = np.zeros((H, W, 3), np.float32)
     ids = rt.RayIds(W * H * sqrt_rpp * sqrt_rpp, scene.n_point_lights) if want_ids else None
     s = ids.as_struct() if ids is not None else None

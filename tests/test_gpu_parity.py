@@ -126,11 +126,7 @@ def test_batched_render_equals_single_batch(rt, backend, scene_path):
     scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=200, image_height=150, recursion_depth=6)
     dev = backend.upload(scene)
     one, ids_one, s_one = dev.render(3, want_ids=True)
-    os.environ["RT_BATCH_SAMPLES"] = str(32 * 32 * 9 * 5)  # five tiles per batch
-    try:
-        many, ids_many, s_many = dev.render(3, want_ids=True)
-    finally:
-        del os.environ["RT_BATCH_SAMPLES"]
+    many, ids_many, s_many = dev.render(3, want_ids=True, batch_samples=32 * 32 * 9 * 5)  # five tiles per batch
     assert s_many.kernel_launches[rt.KERNEL_CLASSES.index("resolve")] > s_one.kernel_launches[rt.KERNEL_CLASSES.index("resolve")]
     assert np.array_equal(one.pixels, many.pixels)
     for f in rt.ID_FIELDS:
@@ -185,22 +181,125 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
 
 @pytest.mark.parametrize("n,weight", [(2, 0), (5, 6)])
 def test_render_multi_in_one_process(rt, scene_path, n, weight):
-    """rt_render_multi: n backends (here on one device), one host thread each, tiles collected on the first:
-    the frame and the ray counts of the unsplit render."""
+    """rt_multi_create / rt_render_multi: n backends (here on one device), one host thread each, the tiles
+    of parts 1.. brought to the first part's buffer by grouped RCCL send / receive pairs (to the same
+    device here, over xGMI between devices): the frame and the ray counts of the unsplit render."""
     scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=250, image_height=170, recursion_depth=6)
     backends = [rt.Backend(0) for _ in range(n)]
     devs = [b.upload(scene) for b in backends]
     whole, _, whole_stats = devs[0].render(2)
     a = devs[0].render_args(2, tile=(16, 16), part0_weight=weight)
-    fb, stats = rt.render_multi(devs, a)
+    multi = rt.Multi(devs)
+    fb, stats = multi.render(a)
     assert np.array_equal(fb, whole.pixels)
     assert stats.total_rays() == whole_stats.total_rays()
+    # again without statistics (nothing waits before the gather) and into page-locked memory
+    pinned = rt.HostBuffer((170, 250, 3))
+    for _ in range(3):
+        pinned.array[:] = 0.0
+        fb2, none = multi.render(a, out=pinned.array, want_stats=False)
+        assert none is None and np.array_equal(fb2, whole.pixels)
+    # another frame size through the same handle's buffers is refused by the scenes, not by the handle:
+    # the jittered frame of the same size must work
+    aj = devs[0].render_args(2, antialias_method=1, seed=5, tile=(16, 16), part0_weight=weight)
+    fbj, _ = multi.render(aj)
+    assert np.array_equal(fbj, devs[0].render(2, antialias_method=1, seed=5)[0].pixels)
+    multi.close()
     with pytest.raises(rt.RtError):  # a backend twice
-        rt.render_multi([devs[0], devs[0]], a)
+        rt.Multi([devs[0], devs[0]])
+    pinned.close()
     for d in devs:
         d.close()
     for b in backends:
         b.close()
+
+
+def test_comm_gather_with_one_rank(rt, backend, scene_path):
+    """rt_comm_*: the communicator of a one-process-per-GPU launch with a single rank -- rank 0 sends
+    its tiles to itself through RCCL and un-tiles them; what bench.py --gpus N does on every rank."""
+    import torch
+
+    W, H, tile = 250, 170, 16
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    whole, _, _ = dev.render(2)
+    comm = rt.Comm(backend, rt.Comm.make_id(), 0, 1)
+    a = dev.render_args(2, tile=(tile, tile), part=(0, 1))
+    # part_count 1 renders in image layout, so split the frame in 3 and gather one part at a time through the comm
+    parts = 3
+    a3 = dev.render_args(2, tile=(tile, tile), part=(0, parts))
+    _, _, stride = dev.partition_info(a3)
+    block = stride * tile * tile * 3
+    st = torch.cuda.Stream()
+    mine = torch.zeros(block, dtype=torch.float32, device="cuda")
+    gathered = torch.zeros(parts * block, dtype=torch.float32, device="cuda")
+    fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(parts):
+        ap = dev.render_args(2, tile=(tile, tile), part=(p, parts))
+        dev.render_device(ap, mine.data_ptr(), stream=st.cuda_stream)
+        comm.gather(mine.data_ptr(), block, gathered.data_ptr() + p * block * 4, stream=st.cuda_stream)
+    dev.untile_device(a3, gathered.data_ptr(), fb.data_ptr(), stream=st.cuda_stream)
+    backend.sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(fb.cpu().numpy().reshape(H, W, 3), whole.pixels)
+    comm.close()
+    dev.close()
+
+
+def test_async_render_into_pinned_memory(rt, backend, scene_path):
+    """rt_render_async + rt_backend_sync: frames enqueued with their copy to page-locked host memory;
+    rt_render recognises such memory too and skips its staging copy."""
+    scene = rt.parse_scene_file(scene_path("bunny_small"), image_width=200, image_height=150, recursion_depth=6)
+    dev = backend.upload(scene)
+    ref, _, _ = dev.render(3)
+    bufs = [rt.HostBuffer((150, 200, 3)) for _ in range(2)]
+    a = dev.render_args(3)
+    for b in bufs:
+        dev.render_async(a, b)  # two frames back to back on the backend's stream
+    backend.sync()
+    for b in bufs:
+        assert np.array_equal(b.array, ref.pixels)
+    direct, _, none = dev.render(3, want_stats=False, out=bufs[0].array)
+    assert none is None and np.array_equal(direct.pixels, ref.pixels)
+    plain, _, _ = dev.render(3, want_stats=False)  # pageable destination, no statistics
+    assert np.array_equal(plain.pixels, ref.pixels)
+    with pytest.raises(rt.RtError):  # pageable memory cannot be written by the device
+        lib = rt.lib()
+        arr = np.zeros((150, 200, 3), np.float32)
+        rc = lib.rt_render_async(backend.handle, dev.handle, C.byref(a), arr.ctypes.data)
+        if rc != 0:
+            raise rt.RtError(rc, lib.rt_last_error().decode())
+    with pytest.raises(rt.RtError):  # parts are not whole frames
+        dev.render_async(dev.render_args(3, part=(0, 2)), bufs[0])
+    for b in bufs:
+        b.close()
+    dev.close()
+
+
+def test_fused_and_separate_shadow_kernels_agree(rt, backend, scene_path):
+    """Fast mode traces the shadow rays and sums the lights in one kernel; RT_RENDER_UNFUSED_SHADOWS keeps
+    one launch per light and a separate accumulate launch, RT_RENDER_NO_PACKETS the per-lane kernels,
+    RT_RENDER_ROW_MAJOR_PIXELS the plain pixel order.  None of them may change a pixel or a count."""
+    for name in ("mixed_features", "bunny_small", "spheres_1K"):
+        scene = rt.parse_scene_file(scene_path(name), image_width=200, image_height=150, recursion_depth=6)
+        dev = backend.upload(scene)
+        base, ids0, st0 = dev.render(3, want_ids=True)
+        for flags in (rt.RT_RENDER_UNFUSED_SHADOWS, rt.RT_RENDER_NO_PACKETS, rt.RT_RENDER_ROW_MAJOR_PIXELS):
+            fb, ids, st = dev.render(3, want_ids=True, flags=flags)
+            assert np.array_equal(fb.pixels, base.pixels), (name, flags)
+            assert np.array_equal(ids.shadow_shape >= 0, ids0.shadow_shape >= 0) and np.array_equal(ids.shadow_shape == -2, ids0.shadow_shape == -2)
+            assert np.array_equal(ids.primary_tri, ids0.primary_tri) and st.total_rays() == st0.total_rays()
+        dev.close()
+    scene = rt.parse_scene_file(scene_path("bunny_small"), image_width=200, image_height=150, recursion_depth=6)
+    a = backend.upload(scene)
+    b = backend.upload(scene, flags=rt.RT_UPLOAD_REFERENCE_MESH_TREES)
+    fa, ia, _ = a.render(3, want_ids=True)
+    fb_, ib, _ = b.render(3, want_ids=True)
+    assert parity.image_metrics(fa.pixels, fb_.pixels)["max_abs_diff"] <= 1
+    assert ((ia.primary_shape == ib.primary_shape) & (ia.primary_tri == ib.primary_tri)).mean() >= 0.9999
+    a.close()
+    b.close()
 
 
 def test_untile_of_frames_gathered_together(rt, backend, scene_path):
@@ -352,11 +451,10 @@ def test_progress_callback_counts_finished_pixels(rt, backend, scene_path):
     scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=200, image_height=150, recursion_depth=3)
     dev = backend.upload(scene)
     seen = []
-    os.environ["RT_BATCH_SAMPLES"] = str(32 * 32 * 4 * 6)  # six tiles per batch
-    try:
-        fb, _, _ = dev.render(2, progress=lambda done, total: seen.append((done, total)))
-    finally:
-        del os.environ["RT_BATCH_SAMPLES"]
+    fb, _, _ = dev.render(2, progress=lambda done, total: seen.append((done, total)), batch_samples=32 * 32 * 4 * 6)  # six tiles per batch
+    quiet = []
+    dev.render(2, progress=lambda done, total: quiet.append((done, total)), batch_samples=32 * 32 * 4 * 6, want_stats=False)
+    assert quiet == seen  # the callback does not depend on statistics being asked for
     assert len(seen) == 6  # 7 x 5 = 35 tiles
     assert all(t == 200 * 150 for _, t in seen)
     assert [d for d, _ in seen] == sorted(d for d, _ in seen) and seen[-1][0] == 200 * 150 and seen[0][0] > 0

@@ -82,14 +82,13 @@ def test_recursion_depth_limits_mirror_bounces(rt, scene_path):
         assert ids.bounces.max() <= depth
 
 
-def test_fast_mesh_trees_change_no_hit(rt, scene_path, monkeypatch):
+def test_fast_mesh_trees_change_no_hit(rt, scene_path):
     """The fast mode's surface-area mesh trees against the reference's trees walked by the same fast
-    code (RT_MESH_SAH=0 at scene flattening): the same closest hits -- a tree only culls -- except
-    where two triangles tie in fp32 along a shared edge, and the same image."""
+    code (RT_UPLOAD_REFERENCE_MESH_TREES at scene flattening): the same closest hits -- a tree only
+    culls -- except where two triangles tie in fp32 along a shared edge, and the same image."""
     sc = rt.parse_scene_file(scene_path("bunny_small"), image_width=160, image_height=120, recursion_depth=4)
     fb_a, ids_a, st_a = HS.render(sc, 2, mode=rt.RT_MODE_FAST)
-    monkeypatch.setenv("RT_MESH_SAH", "0")
-    fb_b, ids_b, st_b = HS.render(sc, 2, mode=rt.RT_MODE_FAST)
+    fb_b, ids_b, st_b = HS.render(sc, 2, mode=rt.RT_MODE_FAST, upload_flags=rt.RT_UPLOAD_REFERENCE_MESH_TREES)
     same = (ids_a.primary_shape == ids_b.primary_shape) & (ids_a.primary_tri == ids_b.primary_tri)
     assert same.mean() >= 0.9999, same.mean()
     assert np.array_equal(ids_a.shadow_shape >= 0, ids_b.shadow_shape >= 0) or \
