@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""Benchmark of the render hot path: rays/s (camera + mirror + shadow rays).
+"""Benchmark of the render hot path: rays/s (camera + mirror + shadow rays) of frames DELIVERED TO
+HOST MEMORY, which is what the reference's render() returns (render.rs:7-23).
 
     python bench.py --gpus 1 --steps 200 --warmup 3
+    python bench.py --gpus N ...          starts N rank processes itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step is one render of the whole frame with the scene already resident in HBM.
-With N > 1 the frame is cut into interleaved tiles, rank r renders the tiles of
-part r into a compact device buffer, an RCCL gather brings the buffers to rank 0
-(one gather for the frames in flight together) and a kernel there restores the
-image layout of every frame; total work is fixed, so scaling is "strong".  Rank 0
-prints one JSON line.
+A step is one render of the whole frame with the scene already resident in HBM, ending with the
+frame in page-locked host memory.  One GPU: rt_render_async on FLIGHTS backends in turn, so the copy
+of frame k over the bus overlaps the kernels of frame k+1.  N > 1: the frame is cut into interleaved
+tiles, rank r renders the tiles of part r into a compact device buffer, the library's RCCL gather
+(rt_comm_gather: grouped ncclSend / ncclRecv) brings the buffers to rank 0, a kernel there restores
+the image layout and the frame is copied to host memory; total work is fixed, so scaling is
+"strong".  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
@@ -18,6 +21,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +31,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
+CLOCK_GHZ = 2.4        # MI355X peak engine clock
+SIMDS = 1024           # 256 compute units x 4
+CUS = 256
 
 WORKLOADS = {
     # name: (scene, width, height, sqrt_rpp, depth, tile, description)
@@ -39,6 +47,10 @@ WORKLOADS = {
     "simple_sphere_scene": ("simple_sphere_scene", 1000, 1000, 3, 6, 40, "simple_sphere_scene 1000x1000 rpp9 depth6"),
 }
 
+KERNEL_OF_CLASS = {"trace_shadow": ("k_shadow_shade_packet", "k_trace_packet<1,", "k_trace_fast<1>", "k_trace_shadow"),
+                   "trace_closest": ("k_trace_packet<0,", "k_trace_fast<0>", "k_trace_closest"),
+                   "shade": ("k_shade",)}
+
 
 def algorithmic_bytes(workload):
     path = os.path.join(ROOT, "bench", "algorithmic_bytes.json")
@@ -50,32 +62,20 @@ def algorithmic_bytes(workload):
         return None
 
 
-def measured_counters(workload, kernel_class):
-    """Counter figures of the dominant kernel from the committed PMC profile of this same command
-    (profiles/pmc_traffic.json): HBM GB/s actually moved, L2 hit rate, VALU lane utilisation; or None."""
+def pmc_profile(workload, kernel_class):
+    """The committed counter profile of this workload (profiles/pmc_traffic.json, written by
+    tools/summarize_pmc.py from separate rocprofv3 --pmc passes over `bench.py --flights 1`): figures
+    of the kernel with the most device time, and the HBM bytes of a whole frame.  None when the
+    profile is missing or was taken for another dominant kernel."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             entry = json.load(f).get(workload)
-        if measured_traffic(workload, kernel_class) is None:
-            return None
-        return {k: entry.get(k) for k in ("hbm_gbs", "l2_hit_rate", "valu_lane_utilisation")}
+        if entry and entry.get("kernel", "").startswith(KERNEL_OF_CLASS.get(kernel_class, ())):
+            return entry
     except Exception:
-        return None
-
-
-def measured_traffic(workload, kernel_class):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
-    command (profiles/pmc_traffic.json, written by tools/summarize_pmc.py), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    want = {"trace_shadow": ("k_trace_packet<1,", "k_trace_fast<1>", "k_trace_shadow"),
-            "trace_closest": ("k_trace_packet<0,", "k_trace_fast<0>", "k_trace_closest")}.get(kernel_class, ())
-    try:
-        with open(path) as f:
-            entry = json.load(f).get(workload)
-        return entry["bytes"] if entry and entry.get("kernel", "").startswith(want) else None
-    except Exception:
-        return None
+        pass
+    return None
 
 
 def measured_hbm_gbs(torch):
@@ -111,6 +111,20 @@ def cpu_baseline(rt, scene_name, depth, sample_px, n, threads):
     return sum(counters["rays"]) / dt, dt
 
 
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (torch.distributed.run,
+    one per GPU) as children of this process, which has not touched the GPU, pass their output
+    through (rank 0 prints the JSON line) and leave with their exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,8 +132,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--flights", type=int, default=0, help="frames in flight per GPU (0: 4, or 8 from five GPUs on)")
+    ap.add_argument("--render-flags", type=int, default=0, help="RtRenderArgs.flags (RT_RENDER_*), for comparisons")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     # A frame cut into more than four parts leaves each GPU launches so small that a kernel lasts as
     # long as its slowest wave, and a frame's chain of kernels (0.5-0.7 ms for a 1/8 frame alone) sets
@@ -141,18 +160,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # RT_BENCH_MULTI_PATH=1 runs the N > 1 code (process group, grouped gather, un-tile) with a single
-    # rank, as a check of that path on a one-GPU machine; the figures are then not the N = 1 benchmark.
+    # RT_BENCH_MULTI_PATH=1 runs the N > 1 code (process group, RCCL communicator of the library, grouped
+    # gather, un-tile) with a single rank, as a check of that path on a one-GPU machine; the figures
+    # are then not the N = 1 benchmark.
     multi = world > 1 or os.environ.get("RT_BENCH_MULTI_PATH", "0") == "1"
+    if multi and "RANK" not in os.environ:  # the one-rank check, started without a launcher
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU implementation")
-    if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":
+    # RT_BENCH_BACKEND=gloo: rehearsal of the N > 1 bookkeeping with several ranks on ONE GPU; the tiles
+    # then travel through host memory, because RCCL does not put two ranks on one device
+    staged = os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo"
+    if staged:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if multi:
-        if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":  # rehearsal of the N > 1 path on a single GPU
+        if staged:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -168,91 +195,111 @@ def main():
     scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
                                 recursion_depth=depth)
     # FLIGHTS frames are in flight at a time, each with a backend (ray queues), a stream and
-    # output buffers of its own: the tail of one frame's kernels (a few long-running waves) then
-    # overlaps the next frame's work instead of idling the GPU.  Measured on one MI355X for this
-    # frame cut into 8 parts: 0.54 ms per part-frame with one frame in flight, 0.28 ms with four
-    # (the whole frame: 1.82 -> 1.76 ms).
-    # frames in flight per GPU (whole frame: 3 to 8 measure within 2 % of each other, 2 is 9 % slower)
-    FLIGHTS = int(os.environ.get("RT_BENCH_FLIGHTS", "8" if many_parts else "4"))
+    # output buffers of its own: the tail of one frame's kernels (a few long-running waves) and its
+    # copy to the host then overlap the next frame's work instead of idling the GPU.
+    FLIGHTS = args.flights or int(os.environ.get("RT_BENCH_FLIGHTS", "8" if many_parts else "4"))
     backends = [rt.Backend(local_rank) for _ in range(FLIGHTS)]
     t_up = time.perf_counter()
     devs = [be.upload(scene) for be in backends]
     upload_s = (time.perf_counter() - t_up) / FLIGHTS
     dev = devs[0]
     mode = rt.RT_MODE_FAST if args.mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
-    # Rank 0 also receives the other ranks' tiles and restores the image layout of every frame: with
-    # 1/8 frames that is a tenth of its time even when the gather is a local copy
-    # (tools/gather_host_cost.py: 0.184 ms per frame against 0.169 for the render alone), so from five
-    # GPUs on it takes 6/8 of the share the others get: its whole step then measures 0.152 ms, which
-    # leaves room for what a real seven-peer receive adds, and the other parts 0.164-0.180 ms
-    # (equal shares: 0.165-0.179).
+    # Rank 0 also receives the other ranks' tiles, restores the image layout of every frame and sends it
+    # to the host: with 1/8 frames that is a tenth of its time even when the gather is a local copy,
+    # so from five GPUs on it takes 6/8 of the share the others get.
     part0_weight = int(os.environ.get("RT_BENCH_PART0_WEIGHT", "6" if many_parts else "0"))
-    rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight)
+    rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight,
+                            flags=args.render_flags)
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
     tile_floats = tile * tile * 3
+    fb_floats = W * H * 3
 
     # Streams of our own: the backend treats a null stream handle as "use the backend's private
-    # stream", which would not be ordered with torch's copies and collectives.
+    # stream", which would not be ordered with torch's copies.
     streams = [torch.cuda.Stream() for _ in range(FLIGHTS)]
     torch.cuda.set_stream(streams[0])
-    staged = multi and dist.get_backend() != "nccl"  # rehearsal on one GPU: gather through host memory (gloo)
     counter = [0]
+    comm = None
 
     if not multi:
-        fbs = [torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") for _ in range(FLIGHTS)]
-        fb = fbs[0]
+        host = [rt.HostBuffer((H, W, 3)) for _ in range(FLIGHTS)]
+        fbs = [torch.zeros(fb_floats, dtype=torch.float32, device="cuda") for _ in range(FLIGHTS)]
+        delivered = host[0].array
 
         def step(want_stats):
+            """One frame into page-locked host memory (the benchmarked path): rt_render_async on the next
+            backend, after waiting for that backend's previous frame; with statistics, a blocking rt_render."""
             b = counter[0] % FLIGHTS
             counter[0] += 1
-            return devs[b].render_device(rargs, fbs[b].data_ptr(), stream=streams[b].cuda_stream, want_stats=want_stats)
+            if want_stats:
+                return devs[b].render(n, mode=mode, tile=(tile, tile), flags=args.render_flags, out=host[b].array)[2]
+            backends[b].sync()
+            devs[b].render_async(rargs, host[b])
+            return None
+
+        def step_device():
+            """The same frame left in device memory (no copy): rt_render_device on streams of our own."""
+            b = counter[0] % FLIGHTS
+            counter[0] += 1
+            devs[b].render_device(rargs, fbs[b].data_ptr(), stream=streams[b].cuda_stream)
 
         def drain():
-            pass
+            for be in backends:
+                be.sync()
     else:
         # GROUP consecutive frames are gathered together: every rank renders its part of each into one
         # buffer, ONE gather brings all of them to rank 0, and rank 0 restores the image layout frame
-        # by frame on a side stream.  Two groups alternate, so the gather and un-tiling of one overlap
-        # the renders of the other.  Measured on one MI355X with a one-rank RCCL group
-        # (tools/gather_host_cost.py: the gather degenerates to a local copy, so this is a lower bound),
-        # per 1/8 frame: render alone 0.169 ms; with a gather and an un-tile per frame 0.245 ms; per
-        # group of 8 frames 0.191 ms, of 16 frames 0.183 ms (of which the un-tile kernels are 0.010).
+        # by frame on a side stream and sends each frame to page-locked host memory.  Two groups
+        # alternate, so the gather, un-tiling and copies of one overlap the renders of the other.
+        # Measured on one MI355X with a one-rank communicator (the gather degenerates to a local copy,
+        # so this is a lower bound), per 1/8 frame: render alone 0.169 ms; with a gather and an un-tile
+        # per frame 0.245 ms; per group of 8 frames 0.191 ms, of 16 frames 0.183 ms.
         GROUP = 2 * FLIGHTS
         part_floats = stride * tile_floats
         part = [torch.zeros(GROUP * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
         root = rank == 0
         gathered = [torch.zeros(world * GROUP * part_floats, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
-        fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if root else None
+        fb = [torch.zeros(fb_floats, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
+        host_fb = [torch.zeros(fb_floats, dtype=torch.float32).pin_memory() if root else None for _ in range(2)]
+        delivered = host_fb[0].numpy().reshape(H, W, 3) if root else None
         joiner = torch.cuda.Stream()     # waits for the frames of a group, then issues their gather
-        side = torch.cuda.Stream()       # rank 0: waits for a gather and restores the image layout
+        side = torch.cuda.Stream()       # rank 0: waits for a gather, restores the image layout, copies to the host
         sent = [None, None]              # event: the gather that read part[g] / wrote gathered[g] is done
         untiled = [None, None]           # event: gathered[g] has been consumed
+        last_delivered = [None]          # rank 0: the host buffer that holds the newest frame
+        if not staged:
+            # the library's own RCCL communicator: rank 0 makes the id, the launcher's process group carries it
+            ids = [rt.Comm.make_id() if root else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = rt.Comm(backends[0], ids[0], rank, world)
 
         def flush(g, count):
-            """Gathers the first `count` frames of group g and, on rank 0, un-tiles them."""
+            """Gathers the first `count` frames of group g and, on rank 0, un-tiles them and copies them out."""
             for b in range(min(count, FLIGHTS)):
                 joiner.wait_stream(streams[b])
             mine = part[g][: count * part_floats]
             with torch.cuda.stream(joiner):
                 if staged:  # rehearsal on one GPU: through host memory
-                    host = mine.cpu()
-                    bufs = [torch.empty_like(host) for _ in range(world)] if root else None
-                    dist.gather(host, bufs, dst=0)
+                    cpu = mine.cpu()
+                    bufs = [torch.empty_like(cpu) for _ in range(world)] if root else None
+                    dist.gather(cpu, bufs, dst=0)
                     if root:
                         gathered[g][: world * count * part_floats].copy_(torch.cat(bufs))
                 else:
                     if untiled[g] is not None:
                         joiner.wait_event(untiled[g])
-                    into = [gathered[g][r * count * part_floats:(r + 1) * count * part_floats] for r in range(world)] if root else None
-                    dist.gather(mine, into, dst=0)  # returns once enqueued; this stream then waits for RCCL's
+                    # rank r's frames land at r * count blocks: [rank][frame][block]
+                    comm.gather(mine.data_ptr(), count * part_floats, gathered[g].data_ptr() if root else 0, stream=joiner.cuda_stream)
                 sent[g] = joiner.record_event()
             if root:
                 with torch.cuda.stream(side):
                     side.wait_event(sent[g])
-                    # gathered[g] holds [rank][frame][block]: frame f starts at f blocks, the ranks lie count blocks apart
+                    # frame f starts at f blocks, the ranks lie count blocks apart
                     for f in range(count):
-                        dev.untile_device(rargs, gathered[g].data_ptr() + f * part_floats * 4, fb.data_ptr(),
+                        dev.untile_device(rargs, gathered[g].data_ptr() + f * part_floats * 4, fb[f & 1].data_ptr(),
                                           stream=side.cuda_stream, part_pitch_floats=count * part_floats)
+                        host_fb[f & 1].copy_(fb[f & 1], non_blocking=True)
+                    last_delivered[0] = host_fb[(count - 1) & 1]
                     untiled[g] = side.record_event()
 
         def step(want_stats):
@@ -275,6 +322,8 @@ def main():
                 counter[0] = (k // GROUP + 1) * GROUP  # the next frame starts a group
             torch.cuda.current_stream().wait_stream(joiner)
             torch.cuda.current_stream().wait_stream(side)
+            for be in backends:
+                be.sync()
 
     def fence():
         drain()
@@ -282,33 +331,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        return time.perf_counter() - t0
+
     # Warm-up frames are rendered with the backend's full statistics (an event pair around every
-    # kernel, counters read back, the host waits for each frame): they give the ray counts, which
-    # are the same for every frame, and the split of a frame over the kernel classes.  The timed
-    # frames are enqueued back to back without waiting; only the dominant kernel class carries an
-    # event pair there (its durations are collected after the loop for the roofline), because
-    # every pair drains the pipeline for a few microseconds.
-    # Every flight twice at least: a backend's first frame touches its buffers for the first time, and
-    # the kernel split is read from the last warm-up frame.
+    # kernel, counters read back, the host waits for each frame, so every kernel runs alone on the
+    # GPU): they give the ray counts, which are the same for every frame, and the split of a frame
+    # over the kernel classes.  Every flight twice at least: a backend's first frame touches its
+    # buffers for the first time.
     warm_stats = [step(True) for _ in range(max(args.warmup, 2 * FLIGHTS))]
     fence()
-    k_warm = [warm_stats[-1].kernel_ms[k] for k in range(rt.RT_K_COUNT)]
+    s0 = warm_stats[-1]  # the last warm-up frame: caches and clocks have settled
+    k_warm = [s0.kernel_ms[k] for k in range(rt.RT_K_COUNT)]
     dom = max(range(len(rt.KERNEL_CLASSES)), key=lambda k: k_warm[k])
-    rargs.timed_classes = 1 << dom
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(False)
-    fence()
-    elapsed = time.perf_counter() - t0
-    timed = rt.RtStats()
-    for be in backends:
-        part_t = be.collect_timings()
-        for k in range(rt.RT_K_COUNT):
-            timed.kernel_ms[k] += part_t.kernel_ms[k]
-            timed.kernel_launches[k] += part_t.kernel_launches[k]
-    rargs.timed_classes = 0
-    stats = warm_stats[-1:]  # the last warm-up frame: caches and clocks have settled
-    rays_local = float(warm_stats[-1].total_rays() * args.steps)
+    dom_name = rt.KERNEL_CLASSES[dom]
+    rays_per_frame_local = float(s0.total_rays())
+
+    # ---- the timed region: EXACTLY args.steps frames, each delivered to host memory
+    elapsed = timed(lambda: step(False), args.steps)
+
+    extra = {}
+    solo_ms, solo_launches = None, 0
+    if not multi:
+        # the same frames left in device memory, FLIGHTS in flight (no copy to the host) ...
+        for _ in range(FLIGHTS):
+            step_device()
+        el_dev = timed(step_device, args.steps)
+        extra["value_device_resident"] = rays_per_frame_local * args.steps / el_dev
+        extra["ms_per_step_device_resident"] = el_dev / args.steps * 1e3
+        # ... and one frame at a time through the blocking entry point, rt_render into page-locked memory
+        single = max(20, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(single):
+            devs[0].render(n, mode=mode, tile=(tile, tile), flags=args.render_flags, want_stats=False, out=host[0].array)
+        el_single = time.perf_counter() - t0
+        extra["value_single_frame"] = rays_per_frame_local * single / el_single
+        extra["ms_per_step_single_frame"] = el_single / single * 1e3
+        # Duration of the dominant kernel for the roofline: frames one at a time (the kernel has the GPU
+        # to itself, as in the profiles under profiles/), an event pair around that kernel class only.
+        rargs.timed_classes = 1 << dom
+        for _ in range(single):
+            devs[0].render_device(rargs, fbs[0].data_ptr(), stream=streams[0].cuda_stream)
+            backends[0].sync()
+        t = backends[0].collect_timings()
+        rargs.timed_classes = 0
+        solo_ms = t.kernel_ms[dom] / max(t.kernel_launches[dom], 1)
+        solo_launches = int(t.kernel_launches[dom])
 
     # Outside the timed region: the gathered frame must be bit-identical with the same frame rendered
     # whole on rank 0 (static tile map, ordered per-pixel sums).
@@ -316,16 +389,19 @@ def main():
     if multi and world == 1:
         frame_check = "not applicable: a single part is rendered in image layout, not tile by tile"
     elif multi and rank == 0:
-        whole = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        whole = torch.zeros(fb_floats, dtype=torch.float32, device="cuda")
         dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile)), whole.data_ptr(), stream=streams[0].cuda_stream)
         torch.cuda.synchronize()
-        if not torch.equal(whole, fb):
-            raise SystemExit(f"gathered frame differs from the single-GPU frame in {int((whole != fb).sum())} values")
-        frame_check = "gathered frame bit-identical with rank 0's single-GPU render"
+        last = last_delivered[0]
+        if not torch.equal(whole.cpu(), last):
+            raise SystemExit(f"gathered frame differs from the single-GPU frame in {int((whole.cpu() != last).sum())} values")
+        frame_check = "gathered frame (in host memory) bit-identical with rank 0's single-GPU render"
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([rays_per_frame_local * args.steps], dtype=torch.float64, device="cuda")
     if multi:
+        if staged:
+            t, rays = t.cpu(), rays.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -333,43 +409,56 @@ def main():
 
     if rank == 0:
         value = total_rays / elapsed
-        s0 = stats[0]
-        n_stat = len(stats)  # frames the kernel timings below were taken over
-        # dominant kernel = the class with the most device time on this rank (warm-up frames);
-        # its launch duration is the one measured in the timed frames
-        k_ms = [sum(s.kernel_ms[k] for s in stats) for k in range(rt.RT_K_COUNT)]
-        k_n = [sum(s.kernel_launches[k] for s in stats) for k in range(rt.RT_K_COUNT)]
-        dom_name = rt.KERNEL_CLASSES[dom]
-        avg_ms = timed.kernel_ms[dom] / max(timed.kernel_launches[dom], 1)
+        ms_per_step = elapsed / args.steps * 1e3
+        k_ms = [s0.kernel_ms[k] for k in range(rt.RT_K_COUNT)]
+        k_n = [s0.kernel_launches[k] for k in range(rt.RT_K_COUNT)]
         ab = algorithmic_bytes(args.workload)
-        roofline = None
+        roofline = roofline_issue = None
+        hbm_true = None
+        if solo_ms is None:  # N > 1: the instrumented warm-up frame's figure (its kernels also ran alone)
+            solo_ms = k_ms[dom] / max(k_n[dom], 1)
+        prof = pmc_profile(args.workload, dom_name) if not multi else None
         if ab is not None and dom_name in ("trace_closest", "trace_shadow"):
             if dom_name == "trace_shadow":
                 bytes_per_step = s0.shadow_rays * ab["shadow"]["bytes_per_ray"]
-                launches_per_step = max(k_n[dom] // n_stat, 1)
             else:
                 bytes_per_step = (s0.primary_rays * ab["primary"]["bytes_per_ray"]
                                   + s0.secondary_rays * ab["secondary"]["bytes_per_ray"])
-                launches_per_step = max(k_n[dom] // n_stat, 1)
-            # launches of one step share the step's rays; price the mean launch
-            bytes_per_launch = bytes_per_step / launches_per_step
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, dom_name) if not multi else None,
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                        "launches_timed": int(timed.kernel_launches[dom])}
-            # In the timed region the kernels of FLIGHTS frames share the GPU, so one launch lasts
-            # longer than it would alone.  The same kernel alone on the GPU (last warm-up frame):
-            alone_ms = k_ms[dom] / max(k_n[dom], 1)
-            alone = bytes_per_launch / (alone_ms * 1e-3) / 1e9
-            roofline["alone_on_the_gpu"] = {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS}
-            if not multi:
-                roofline["counters"] = measured_counters(args.workload, dom_name)  # rocprofv3 --pmc passes, profiles/
-            if not multi:
-                torch.cuda.set_stream(torch.cuda.default_stream())
-                hbm = measured_hbm_gbs(torch)
-                roofline["peak_measured"] = hbm  # copy / triad on this box, GB/s
-                roofline["frac_of_measured"] = achieved / hbm
+            launches_per_step = max(k_n[dom], 1)
+            bytes_per_launch = bytes_per_step / launches_per_step  # launches of one step share the step's rays
+            achieved = bytes_per_launch / (solo_ms * 1e-3) / 1e9
+            roofline = {
+                "bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": prof["bytes"] if prof else None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": solo_ms,
+                "launches_timed": solo_launches or int(k_n[dom]),
+                "duration_from": "HIP events around this kernel class on its launch stream, frames rendered one at a "
+                                 "time after the timed region (the kernel alone on the GPU, as in profiles/*_solo)",
+                "frac_above_1_is_expected": "algorithmic bytes are the REFERENCE's traversal (oracle node and primitive "
+                                            "counts x record sizes); this kernel visits about half the nodes in trees "
+                                            "of its own, fetches each once per 64 rays and is served from L2 / MALL. "
+                                            "HBM does not bound it: see roofline_issue and hbm_true_frac",
+            }
+            if prof:
+                roofline["counters"] = {k: prof.get(k) for k in ("hbm_gbs", "l2_hit_rate", "valu_lane_utilisation")}
+                roofline["traffic_frac"] = prof["bytes"] / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if prof and prof.get("valu_wave_insts"):
+            # What does bound the kernel: instruction issue.  A wave64 vector instruction occupies its SIMD
+            # for 4 cycles; the scalar unit of a compute unit issues one instruction per cycle.
+            valu_ms = prof["valu_wave_insts"] * 4.0 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+            scalar_ms = prof["scalar_insts"] / CUS / (CLOCK_GHZ * 1e9) * 1e3
+            bound_ms = max(valu_ms, scalar_ms)
+            roofline_issue = {"kernel": prof["kernel"], "valu_wave_insts": prof["valu_wave_insts"], "scalar_insts": prof["scalar_insts"],
+                              "clock_ghz": CLOCK_GHZ, "valu_bound_ms": valu_ms, "scalar_bound_ms": scalar_ms, "bound_ms": bound_ms,
+                              "kernel_ms": solo_ms, "frac": bound_ms / solo_ms,
+                              "from": "instruction counts per launch: profiles/pmc_traffic.json (rocprofv3 --pmc); kernel_ms: live, as roofline.avg_launch_ms"}
+        if prof and prof.get("frame_hbm_bytes"):
+            hbm_true = prof["frame_hbm_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if roofline is not None and not multi:
+            torch.cuda.set_stream(torch.cuda.default_stream())
+            hbm = measured_hbm_gbs(torch)
+            roofline["peak_measured"] = hbm  # copy / triad on this box, GB/s
+            roofline["frac_of_measured"] = roofline["achieved"] / hbm
         out = {
             "metric": "rays/sec (all ray types), Stanford bunny 1000² spp9 d6, 1/2/4/8 GPUs",
             "value": value,
@@ -377,25 +466,38 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "traversal": args.mode,
+                       "value_is": "frames delivered to page-locked host memory (what render() returns, render.rs:7-23), "
+                                   f"{FLIGHTS} frames in flight",
                        "precision": "fp32 tree search, f64 hit refinement and shading, f32 colour (as the reference's f64 geometry / f32 colour)",
                        "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
                        "part0_weight": part0_weight, "frames_in_flight": FLIGHTS, "hw_queues": int(hw_queues) if hw_queues else "runtime default",
+                       "rccl_ranks": dist.get_world_size() if multi else 1,
+                       "gather": ("none (one GPU)" if not multi else
+                                  "host memory over gloo (one-GPU rehearsal)" if staged else
+                                  "rt_comm_gather: grouped ncclSend / ncclRecv on the library's RCCL communicator"),
+                       "render_flags": args.render_flags,
                        "scene_upload_ms": upload_s * 1e3,
-                       "kernel_split_from": "warm-up frames (fully instrumented); roofline duration from the timed frames"},
-            "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / n_stat for k in range(len(rt.KERNEL_CLASSES))},
-            "device_ms_per_step": sum(s.render_ms for s in stats) / n_stat,
+                       "kernel_split_from": "last warm-up frame (fully instrumented, every kernel alone on the GPU)"},
+            "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] for k in range(len(rt.KERNEL_CLASSES))},
+            "device_ms_per_step": s0.render_ms,
             "roofline": roofline,
+            "roofline_issue": roofline_issue,
+            "hbm_true_frac": hbm_true,
         }
+        out.update(extra)
         if frame_check:
             out["config"]["frame_check"] = frame_check
+        if not multi:
+            # the delivered frame is a frame: compare a few pixels of it with the device copy's statistics
+            out["config"]["delivered_frame_checksum"] = float(delivered.astype("float64").sum())
         if not multi and not args.no_cpu_baseline:
             # one frame of the benchmarked workload itself on one core (the reference's loop is serial,
             # render.rs:36-50): about 9 s for the bunny frame; the 4K workload is sampled at 1000x1000
@@ -410,6 +512,11 @@ def main():
                                              "sample": f"same scene at 1000x1000 rpp9, OpenMP over pixel columns, {dtN:.1f} s"}
         print(json.dumps(out), flush=True)
 
+    if comm is not None:
+        comm.close()
+    if not multi:
+        for h in host:
+            h.close()
     for d in devs:
         d.close()
     for be in backends:

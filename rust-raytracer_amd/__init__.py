@@ -307,22 +307,22 @@ def _check(rc: int) -> None:
 def _share_rccl_with_torch() -> None:
     """The communicators below load librccl by its soname when the first one is made.  A PyTorch wheel
     bundles a copy (torch/lib/librccl.so) built against its bundled HIP runtime; when that runtime is
-    the one this process holds (see _share_hip_runtime_with_torch), its RCCL must be the one as well,
-    so it is loaded first and the library finds it already mapped."""
+    the one this process holds (see _share_hip_runtime_with_torch), its RCCL must be the one as well.
+    Importing torch BEFORE the first communicator is made takes care of that, and of the order of
+    set-up and tear-down between the two: a process that made a communicator first and imported torch
+    afterwards ended with "double free or corruption" when it exited (seen on MI355X, ROCm 7.2 /
+    torch 2.10)."""
     import importlib.util
+    import sys
 
+    if "torch" in sys.modules:
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         return
-    if spec is None or not spec.submodule_search_locations:
-        return
-    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
-    if os.path.exists(bundled):
-        try:
-            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    if spec is not None:
+        importlib.import_module("torch")
 
 
 class Multi:

@@ -118,12 +118,21 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         if (act == RT_ACT_MIRROR) shade_commit_mirror(Q, bounce, slot, tmp);
         // Lit hits per chunk of RT_LIT_CHUNK samples, for the compaction of the lit table below.  At
         // bounce 0 a wave holds 64 consecutive samples of one chunk: one add per wave.  Later bounces
-        // reach samples in queue order: one add per lit lane (rare, and spread over many addresses).
+        // reach samples in queue order, which follows the sample order loosely: the wave adds once per
+        // distinct chunk among its lit lanes (one add per lane made this kernel 1.7x slower on a frame
+        // of mirrors: the lanes of a wave mostly hit the same counter and queue up on it).
+        unsigned long long todo = __ballot(act == RT_ACT_LIT);
         if (bounce == 0) {
-            const unsigned long long lit = __ballot(act == RT_ACT_LIT);
-            if (lit != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(lit));
-        } else if (act == RT_ACT_LIT) {
-            atomicAdd(&Q.block_counts[(uint32_t)Q.q_sample[bounce & 1][idx] / RT_LIT_CHUNK], 1u);
+            if (todo != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(todo));
+        } else if (todo != 0ull) {
+            const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)Q.q_sample[bounce & 1][idx] / RT_LIT_CHUNK : ~0u;
+            while (todo != 0ull) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t which = (uint32_t)__shfl((int)chunk, leader, 64);
+                const unsigned long long same = __ballot(chunk == which);
+                if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&Q.block_counts[which], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
         }
     }
 }
@@ -219,54 +228,74 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
 // origin ids once instead of once per light, and -- what matters most -- puts the f64 arithmetic of
 // the light sums into the issue slots that the tree walk of other waves leaves idle while it waits
 // for its node records.
+//
+// The walk runs at the register budget of eight waves per SIMD with nothing to spare, so nothing but
+// the walk's own state may stay in vector registers across it: a lane's "hidden" bits wait in an
+// LDS word of its own, and everything else about its sample is fetched again where it is needed
+// (`opaque` keeps the compiler from hoisting those fetches, and the addresses they go to, out of
+// the loop over the lights and across the walk).
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
 k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
     const uint32_t count = Q.counters[RT_CNT_LIT];
     const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
     if (blockIdx.x >= n_blocks) return;
-    const uint32_t idx = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+    const uint32_t idx0 = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
     const int rows = S.stack_depth + 1;
-    const bool live = idx < count;
-    const uint32_t sample = live ? Q.lit_list[idx] : 0u;
-    int32_t org_shape = -1, org_tri = -1;
-    uint32_t hidden = 0u;
-    if (live) {
-        org_shape = RT_STREAM_LD(Q.l_shape[sample]);
-        org_tri = RT_STREAM_LD(Q.l_tri[sample]);
-        hidden = RT_STREAM_LD(Q.l_self[sample]);
-    }
+    uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rows + 6 * 64) + threadIdx.x;  // behind the walk's LDS
+    *hidden_slot = 0u;
     const bool want_ids = ids.shadow_shape != nullptr || ids.shadow_tri != nullptr;
     bool ok = true;
     if (!S.disable_shadows) {
         for (int ls = 0; ls < S.n_point_lights; ++ls) {
-            const bool self = ((hidden >> ls) & 1u) != 0u;
-            const bool trace = live && !self;
-            // the hit point is fetched again for every light rather than kept in six registers across the walk
-            D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
-            if (trace) {
-                o = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
-                d = d3(S.lights[S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
-            }
+            const uint32_t idx = opaque(idx0);
+            const bool live = idx < count;
             FastTrav st[1];
-            fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
-            st[0].t = trace ? 1.0f : -__builtin_inff();  // Hit::to_light's bound, or an empty search interval
-            st[0].shape = -1;
-            st[0].tri = -1;
-            st[0].org_shape = org_shape;
-            st[0].org_tri = org_tri;
+            bool self = false;
+            {
+                D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
+                int32_t org_shape = -1, org_tri = -1;
+                bool trace = false;
+                if (live) {
+                    const uint32_t sample = Q.lit_list[idx];
+                    org_shape = RT_STREAM_LD(Q.l_shape[sample]);
+                    org_tri = RT_STREAM_LD(Q.l_tri[sample]);
+                    self = ((RT_STREAM_LD(Q.l_self[sample]) >> ls) & 1u) != 0u;
+                    trace = !self;
+                    if (trace) {
+                        o = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+                        d = d3(S.lights[S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
+                    }
+                }
+                fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
+                st[0].t = trace ? 1.0f : -__builtin_inff();  // Hit::to_light's bound, or an empty search interval
+                st[0].shape = -1;
+                st[0].tri = -1;
+                st[0].org_shape = org_shape;
+                st[0].org_tri = org_tri;
+            }
             ok = packet_traverse<true, 1>(S, st, (float)RT_VERY_SMALL_NUMBER, lds, rows - 1) && ok;
-            if (st[0].shape >= 0) hidden |= 1u << ls;
+            if (st[0].shape >= 0 || self) *hidden_slot |= 1u << ls;
             if (want_ids && live) {
+                const uint32_t sample = Q.lit_list[opaque(idx0)];
                 const size_t at = global_sample(B, sample) * (size_t)S.n_point_lights + (size_t)ls;
-                const int32_t blocker = self ? org_shape : st[0].shape;
+                const int32_t blocker = self ? RT_STREAM_LD(Q.l_shape[sample]) : st[0].shape;
                 if (ids.shadow_shape) ids.shadow_shape[at] = blocker;
                 if (ids.shadow_tri) ids.shadow_tri[at] = self ? -1 : tri_file_index(S, st[0].tri);
             }
         }
     }
     if (!ok) *Q.overflow = 1;
-    if (live) accumulate_masked(S, Q, sample, org_shape, S.disable_shadows ? 0u : hidden);
+    const uint32_t idx = opaque(idx0);
+    if (idx < count) {
+        const uint32_t sample = Q.lit_list[idx];
+        accumulate_masked(S, Q, sample, RT_STREAM_LD(Q.l_shape[sample]), *hidden_slot);
+    }
 }
 
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
@@ -718,7 +747,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
     constexpr int packet_rays = 1;
-    const size_t packet_lds = ((size_t)(std::max(S.stack_depth, 1) + 1) + 6u * 64u * (size_t)packet_rays) * sizeof(int32_t);
+    // stack rows, the world-space rays of a wave inside an instance, and (fused kernel) a word per lane
+    const size_t packet_lds = ((size_t)(std::max(S.stack_depth, 1) + 1) + 6u * 64u * (size_t)packet_rays + 64u) * sizeof(int32_t);
     // a wait per batch: to read the counters for the statistics, or to serve the progress callback
     const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
     const bool wait_batches = stats != nullptr || serve_progress;

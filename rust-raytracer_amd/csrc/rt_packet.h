@@ -69,17 +69,50 @@ __device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav (&s)[R]
     return (nx > half ? 1u : 0u) | (ny > half ? 2u : 0u) | (nz > half ? 4u : 0u) | (mixed ? 8u : 0u);
 }
 
-// Scene records (nodes, triangles, scene-level primitives) are read through the constant address
-// space: nothing writes them while a kernel runs.  A wave-uniform fetch from a plain global pointer
-// is a scalar load only as long as the compiler can prove that no store of the kernel aliases it;
-// anything it cannot see through (a store in a loop around the walk, a builtin that counts as a
-// memory clobber) silently turns every record fetch into per-lane vector loads, 2-5x slower.
+// Record fetches of the walk, spelled out as scalar loads.  The address is the same in all lanes and
+// nothing writes the records, so a scalar load is what the compiler emits too -- as long as the walk
+// is all there is to the kernel.  Inside a loop over lights, with other memory traffic around it, it
+// turns part of every record fetch (the first quarter of a node, the whole triangle) into per-lane
+// vector loads of one and the same address, to save itself register copies; the walk is then 2-3x
+// slower.  Each helper issues the loads of one record and waits for them (the box or triangle test
+// that follows needs them at once anyway).
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) rt_f4 *rt_scene_f4;
-#define RT_SCENE_F4(p) ((rt_scene_f4)(p))
-#else
-typedef const rt_f4 *rt_scene_f4;
-#define RT_SCENE_F4(p) (reinterpret_cast<const rt_f4 *>(p))
+typedef float rt_f8v __attribute__((ext_vector_type(8)));
+typedef float rt_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rt_f4 rt_f4_of(rt_f4v v) { return rt_f4{v[0], v[1], v[2], v[3]}; }
+
+// 64-byte node record at base + off
+__device__ __forceinline__ void rt_fetch_node(const void *base, uint32_t off, rt_f4 &a, rt_f4 &b, rt_f4 &c, rt_f4 &l) {
+    rt_f8v lo, hi;
+    asm("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %3 offset:0x20\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(lo), "=&s"(hi)
+        : "s"(base), "s"(off));
+    a = rt_f4{lo[0], lo[1], lo[2], lo[3]};
+    b = rt_f4{lo[4], lo[5], lo[6], lo[7]};
+    c = rt_f4{hi[0], hi[1], hi[2], hi[3]};
+    l = rt_f4{hi[4], hi[5], hi[6], hi[7]};
+}
+
+// 48-byte record (RtTriXf) at base + off
+__device__ __forceinline__ void rt_fetch_48(const void *base, uint32_t off, rt_f4 &r0, rt_f4 &r1, rt_f4 &r2) {
+    rt_f8v lo;
+    rt_f4v hi;
+    asm("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %3 offset:0x20\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(lo), "=&s"(hi)
+        : "s"(base), "s"(off));
+    r0 = rt_f4{lo[0], lo[1], lo[2], lo[3]};
+    r1 = rt_f4{lo[4], lo[5], lo[6], lo[7]};
+    r2 = rt_f4_of(hi);
+}
+#else  // the host pass of the compiler only parses these
+__device__ inline void rt_fetch_node(const void *base, uint32_t off, rt_f4 &a, rt_f4 &b, rt_f4 &c, rt_f4 &l) {
+    const rt_f4 *n = reinterpret_cast<const rt_f4 *>(reinterpret_cast<const char *>(base) + off);
+    a = n[0]; b = n[1]; c = n[2]; l = n[3];
+}
+__device__ inline void rt_fetch_48(const void *base, uint32_t off, rt_f4 &r0, rt_f4 &r1, rt_f4 &r2) {
+    const rt_f4 *n = reinterpret_cast<const rt_f4 *>(reinterpret_cast<const char *>(base) + off);
+    r0 = n[0]; r1 = n[1]; r2 = n[2];
+}
 #endif
 
 // Inner nodes until a leaf (or the end) comes up.  OCT 0..7: all live rays of the wave have these
@@ -91,8 +124,8 @@ __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastT
                                                uint32_t dir_bits) {
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
     while (cur >= 0) {
-        const rt_scene_f4 n = RT_SCENE_F4(node_base + (uint32_t)cur);
-        const rt_f4 a = n[0], b = n[1], c = n[2], l = n[3];
+        rt_f4 a, b, c, l;
+        rt_fetch_node(node_base, (uint32_t)cur, a, b, c, l);
         bool hl = false, hr = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -201,8 +234,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
             uint32_t at = first * (uint32_t)sizeof(RtTriXf);
             for (uint32_t k = 0; k < cnt; ++k, at += (uint32_t)sizeof(RtTriXf)) {
                 const int32_t gtri = (int32_t)(first + k);
-                const rt_scene_f4 tp = RT_SCENE_F4(tri_base + at);
-                const rt_f4 uv0 = tp[0], uv1 = tp[1], tn = tp[2];
+                rt_f4 uv0, uv1, tn;
+                rt_fetch_48(tri_base, at, uv0, uv1, tn);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float t;
@@ -221,15 +254,15 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
         }
         bool entered = false;
         for (uint32_t k = 0; k < cnt && !entered; ++k) {
-            const rt_scene_f4 pp = RT_SCENE_F4(S.tprims + (size_t)(first + k) * 4);
-            const rt_f4 h = pp[0];
+            rt_f4 h, pp1, pp2, pp3;  // the whole RtTPrim
+            rt_fetch_node(S.tprims, (first + k) * (uint32_t)sizeof(RtTPrim), h, pp1, pp2, pp3);
             const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
                           proto_type = rt_as_int(h.w);
             const bool is_inst = type == RT_SHAPE_INSTANCE;
             if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
                 if (is_inst) {
                     // enter the instance only if some ray of the wave reaches its world box
-                    const rt_f4 f0 = pp[1], f1 = pp[2];
+                    const rt_f4 f0 = pp1, f1 = pp2;
                     bool reach = false;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -241,8 +274,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                 if (k + 1 < cnt) stk.push(rt_make_leaf_ref(first + k + 1, cnt - k - 1));
                 stk.push(RT_REF_EXIT_BLAS);
                 if (is_inst) {
-                    const rt_scene_f4 m = RT_SCENE_F4(S.tprim_xf + (size_t)(first + k) * 3);
-                    const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
+                    rt_f4 r0, r1, r2;
+                    rt_fetch_48(S.tprim_xf, (first + k) * 48u, r0, r1, r2);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const float wox = s[r].ox, woy = s[r].oy, woz = s[r].oz, wdx = s[r].dx, wdy = s[r].dy, wdz = s[r].dz;
@@ -260,7 +293,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                 entered = true;
             } else {
                 // sphere / box / triangle at scene level, possibly instanced (s holds the world rays here)
-                const rt_f4 f0 = pp[1], f1 = pp[2], f2 = pp[3];
+                const rt_f4 f0 = pp1, f1 = pp2, f2 = pp3;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float t;

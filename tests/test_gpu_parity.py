@@ -597,3 +597,24 @@ def test_deferred_kernel_timing(rt, backend, scene_path):
     again = backend.collect_timings()  # nothing pending any more
     assert sum(again.kernel_launches) == 0
     dev.close()
+
+
+def test_bench_multi_gpu_path_with_one_rank(tmp_path):
+    """bench.py's N > 1 code with a single rank (RT_BENCH_MULTI_PATH=1): torch.distributed process group,
+    the library's RCCL communicator made from a broadcast id, grouped gather of several frames,
+    un-tile, copy to the host.  Also: `--gpus 1` started plainly prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_MULTI_PATH="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "2",
+                          "--no-cpu-baseline", "--workload", "spheres_and_triangles"], env=env, capture_output=True, text=True,
+                         timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 1e9
+    assert "rt_comm_gather" in line["config"]["gather"]
