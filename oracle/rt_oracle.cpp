@@ -780,12 +780,21 @@ void antialias(int method, uint64_t seed, uint64_t sample, uint16_t n, uint16_t 
 
 // ---------------------------------------------------------------- render.rs
 
+// Renders the pixels [x0, x0 + ww) x [y0, y0 + wh) of the frame; the framebuffer and the per-sample
+// outputs are indexed inside that window (the whole frame is the window (0, 0, W, H)).  A pixel's
+// value does not depend on the window: the sample index that keys the stochastic methods is the
+// frame-wide one.
 template <typename Real>
-int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int threads, float *fb,
-                const OracleOutputs *out, OracleCounters *counters_out) {
+int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int threads, uint32_t x0, uint32_t y0,
+                uint32_t ww, uint32_t wh, float *fb, const OracleOutputs *out, OracleCounters *counters_out) {
     if (aa_method < 0 || aa_method > 2) return -1;
     Scene<Real> scene(rs);
     const uint32_t W = scene.image_width, H = scene.image_height;
+    if (ww == 0 && wh == 0) {
+        ww = W;
+        wh = H;
+    }
+    if ((uint64_t)x0 + ww > W || (uint64_t)y0 + wh > H) return -1;
     const int npl = scene.n_point_lights;
     const size_t spp = (size_t)n * n;
     Counters total;
@@ -798,13 +807,15 @@ int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int
     {
         Counters local;
 #pragma omp for schedule(dynamic, 4)
-        for (long ii = 0; ii < (long)W; ++ii) {  // render.rs:36-37 (column-major; order does not matter)
+        for (long ii = (long)x0; ii < (long)(x0 + ww); ++ii) {  // render.rs:36-37 (column-major; order does not matter)
             const uint32_t i = (uint32_t)ii;
-            for (uint32_t j = 0; j < H; ++j) {
+            for (uint32_t j = y0; j < y0 + wh; ++j) {
                 Color color(0.0f, 0.0f, 0.0f);  // render.rs:63
+                const size_t window_px = (size_t)(i - x0) + (size_t)(j - y0) * ww;
                 for (uint16_t p = 0; p < n; ++p) {
                     for (uint16_t q = 0; q < n; ++q) {
-                        const size_t s = ((size_t)i + (size_t)j * W) * spp + (size_t)p * n + q;
+                        const size_t s = ((size_t)i + (size_t)j * W) * spp + (size_t)p * n + q;  // frame-wide
+                        const size_t ws = window_px * spp + (size_t)p * n + q;                     // in the outputs
                         Real di, dj;  // render.rs:66
                         antialias<Real>(aa_method, seed, (uint64_t)s, n, p, q, di, dj);
                         Hit<Real> hit = Hit<Real>::make(scene.camera.generate_ray(i, j, di, dj), &scene);
@@ -816,11 +827,11 @@ int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int
                         SampleRecord rec;
                         if (out) {
                             if (out->shadow_shape) {
-                                rec.shadow_shape = out->shadow_shape + s * (size_t)npl;
+                                rec.shadow_shape = out->shadow_shape + ws * (size_t)npl;
                                 for (int l = 0; l < npl; ++l) rec.shadow_shape[l] = -2;
                             }
                             if (out->shadow_tri) {
-                                rec.shadow_tri = out->shadow_tri + s * (size_t)npl;
+                                rec.shadow_tri = out->shadow_tri + ws * (size_t)npl;
                                 for (int l = 0; l < npl; ++l) rec.shadow_tri[l] = -2;
                             }
                         }
@@ -834,16 +845,16 @@ int render_impl(const RtScene &rs, uint16_t n, int aa_method, uint64_t seed, int
                             color += scene.background;
                         }
                         if (out) {
-                            if (out->primary_shape) out->primary_shape[s] = rec.primary_shape;
-                            if (out->primary_tri) out->primary_tri[s] = rec.primary_tri;
-                            if (out->final_shape) out->final_shape[s] = rec.final_shape;
-                            if (out->final_tri) out->final_tri[s] = rec.final_tri;
-                            if (out->bounces) out->bounces[s] = rec.bounces;
+                            if (out->primary_shape) out->primary_shape[ws] = rec.primary_shape;
+                            if (out->primary_tri) out->primary_tri[ws] = rec.primary_tri;
+                            if (out->final_shape) out->final_shape[ws] = rec.final_shape;
+                            if (out->final_tri) out->final_tri[ws] = rec.final_tri;
+                            if (out->bounces) out->bounces[ws] = rec.bounces;
                         }
                     }
                 }
                 color = color / (float)(uint16_t)(n * n);  // render.rs:78
-                float *px = fb + ((size_t)i + (size_t)j * W) * 3;  // framebuffer.rs:21-31
+                float *px = fb + window_px * 3;  // framebuffer.rs:21-31
                 px[0] = color.r;
                 px[1] = color.g;
                 px[2] = color.b;
@@ -920,9 +931,19 @@ int oracle_render_aa(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int ant
                      int geometry_bits, int threads, float *fb_rgb, const OracleOutputs *outputs,
                      OracleCounters *counters) {
     if (!scene || !fb_rgb || sqrt_rays_per_pixel == 0) return -1;
+    return oracle_render_window(scene, sqrt_rays_per_pixel, antialias_method, seed, geometry_bits, threads, 0, 0, 0, 0,
+                                fb_rgb, outputs, counters);
+}
+
+int oracle_render_window(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int antialias_method, uint64_t seed,
+                         int geometry_bits, int threads, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height,
+                         float *fb_rgb, const OracleOutputs *outputs, OracleCounters *counters) {
+    if (!scene || !fb_rgb || sqrt_rays_per_pixel == 0) return -1;
     if (geometry_bits == 32)
-        return render_impl<float>(*scene, sqrt_rays_per_pixel, antialias_method, seed, threads, fb_rgb, outputs, counters);
-    return render_impl<double>(*scene, sqrt_rays_per_pixel, antialias_method, seed, threads, fb_rgb, outputs, counters);
+        return render_impl<float>(*scene, sqrt_rays_per_pixel, antialias_method, seed, threads, x0, y0, width, height,
+                                  fb_rgb, outputs, counters);
+    return render_impl<double>(*scene, sqrt_rays_per_pixel, antialias_method, seed, threads, x0, y0, width, height,
+                               fb_rgb, outputs, counters);
 }
 
 // The generator alone: out = Philox4x32-10(counter, key).

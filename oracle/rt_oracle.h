@@ -46,6 +46,14 @@ int oracle_render_aa(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int ant
                      int geometry_bits, int threads, float *fb_rgb, const OracleOutputs *outputs,
                      OracleCounters *counters);
 
+/* The same for the pixels [x0, x0 + width) x [y0, y0 + height) only (width = height = 0: the whole
+ * frame): fb_rgb holds width*height*3 floats and the per-sample outputs width*height*n*n entries, both
+ * indexed inside the window (pixel (i - x0) + (j - y0) * width).  A pixel's value is the one it has in
+ * the whole frame; the counters cover the window's rays. */
+int oracle_render_window(const RtScene *scene, uint16_t sqrt_rays_per_pixel, int antialias_method, uint64_t seed,
+                         int geometry_bits, int threads, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height,
+                         float *fb_rgb, const OracleOutputs *outputs, OracleCounters *counters);
+
 void oracle_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 
 void oracle_sample_offsets(int method, uint64_t seed, uint64_t sample, uint16_t n, uint16_t p, uint16_t q, double *di,

@@ -54,6 +54,8 @@ def lib():
         L.oracle_render.argtypes = [vp, C.c_uint16, C.c_int, C.c_int, vp, C.POINTER(OracleOutputs), C.POINTER(OracleCounters)]
         L.oracle_render_aa.argtypes = [vp, C.c_uint16, C.c_int, C.c_uint64, C.c_int, C.c_int, vp, C.POINTER(OracleOutputs),
                                        C.POINTER(OracleCounters)]
+        L.oracle_render_window.argtypes = [vp, C.c_uint16, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, vp, C.POINTER(OracleOutputs), C.POINTER(OracleCounters)]
         L.oracle_philox.argtypes = [vp, vp, vp]
         L.oracle_philox.restype = None
         L.oracle_sample_offsets.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint16, C.c_uint16, C.c_uint16,
@@ -77,9 +79,14 @@ def _scene_ptr(scene):
     return C.cast(scene.ptr, C.c_void_p)
 
 
-def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads: int = 0, aa: int = 0, seed: int = 0):
-    """Returns (fb [H,W,3] f32, RayIds | None, counters dict).  aa: 0 normal, 1 jittered, 2 random."""
+def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads: int = 0, aa: int = 0, seed: int = 0,
+           window=None):
+    """Returns (fb [H,W,3] f32, RayIds | None, counters dict).  aa: 0 normal, 1 jittered, 2 random.
+    window = (x0, y0, width, height): only those pixels; fb and ids are then the window's."""
     W, H = scene.image_width, scene.image_height
+    x0 = y0 = 0
+    if window is not None:
+        x0, y0, W, H = (int(v) for v in window)
     fb = np.zeros((H, W, 3), np.float32)
     ids = rt.RayIds(W * H * sqrt_rpp * sqrt_rpp, scene.n_point_lights) if want_ids else None
     outs = OracleOutputs()
@@ -88,10 +95,14 @@ def render(scene, sqrt_rpp: int, want_ids: bool = True, bits: int = 64, threads:
             arr = getattr(ids, f)
             setattr(outs, f, arr.ctypes.data if arr.size else None)
     cnt = OracleCounters()
-    rc = lib().oracle_render_aa(_scene_ptr(scene), sqrt_rpp, int(aa), int(seed), bits, threads, fb.ctypes.data,
-                                C.byref(outs) if ids is not None else None, C.byref(cnt))
+    if window is None:
+        rc = lib().oracle_render_aa(_scene_ptr(scene), sqrt_rpp, int(aa), int(seed), bits, threads, fb.ctypes.data,
+                                    C.byref(outs) if ids is not None else None, C.byref(cnt))
+    else:
+        rc = lib().oracle_render_window(_scene_ptr(scene), sqrt_rpp, int(aa), int(seed), bits, threads, x0, y0, W, H,
+                                        fb.ctypes.data, C.byref(outs) if ids is not None else None, C.byref(cnt))
     if rc != 0:
-        raise RuntimeError(f"oracle_render_aa failed: {rc}")
+        raise RuntimeError(f"oracle render failed: {rc}")
     return fb, ids, cnt.as_dict()
 
 

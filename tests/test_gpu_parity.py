@@ -426,6 +426,92 @@ def test_headline_workload_matches_oracle_at_full_size(rt, backend, scene_path):
     im, idm = parity.assert_parity(fb.pixels, ids, ref_fb, ref_ids, occlusion_only=True, label="bunny 1000^2")
     print("bunny 1000^2 parity:", im, idm)
     assert abs(stats.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
+    # Reference-order mode: shadow rays run to the CLOSEST blocker like light/point.rs:30-40, so the
+    # blocker's shape and triangle are compared one to one, on every one of the 12 M shadow rays.
+    fb_r, ids_r, stats_r = dev.render(3, mode=rt.RT_MODE_REFERENCE_ORDER, want_ids=True)
+    im_r, idm_r = parity.assert_parity(fb_r.pixels, ids_r, ref_fb, ref_ids, occlusion_only=False, label="bunny 1000^2, reference order")
+    print("bunny 1000^2 parity, reference order (blocker ids):", im_r, idm_r)
+    assert idm_r["shadow_rays_compared"] >= 12_000_000 and idm_r["shadow"] >= 0.9999
+    assert abs(stats_r.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
+    dev.close()
+
+
+def test_4k_rpp64_config_whole_and_in_eight_parts(rt, backend, scene_path):
+    """bunny 3840x2160, 64 rays per pixel, depth 6 (530.8 M camera rays, 32 batches of 16 Mi samples):
+    the frame rendered whole equals the frame rendered as 8 interleaved parts and un-tiled, bit for
+    bit and ray for ray; and on four windows of 128 x 96 pixels (silhouettes, ground with shadows,
+    background) the ids of every sample and the 8-bit image match the oracle, in both modes."""
+    import torch
+
+    W, H, n, tile, parts = 3840, 2160, 8, 32, 8
+    spp = n * n
+    scene = rt.parse_scene_file(scene_path("bunny"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    npl = dev.n_point_lights
+    windows = [(1700, 700, 128, 96), (2600, 500, 128, 96), (900, 300, 128, 96), (3000, 1900, 128, 96)]
+    ref = [oracle_lib.render(scene, n, want_ids=True, window=w) for w in windows]
+    assert sum(r[1].primary_shape.min() < 0 for r in ref) >= 1 and sum((r[1].shadow_shape >= 0).any() for r in ref) >= 1
+
+    fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    prim_shape = torch.full((W * H * spp,), -1, dtype=torch.int32, device="cuda")
+    prim_tri = torch.full((W * H * spp,), -1, dtype=torch.int32, device="cuda")
+    sh_shape = torch.full((W * H * spp * npl,), -2, dtype=torch.int32, device="cuda")
+    sh_tri = torch.full((W * H * spp * npl,), -2, dtype=torch.int32, device="cuda")
+    ids = rt.RtRayIds()
+    ids.primary_shape, ids.primary_tri = prim_shape.data_ptr(), prim_tri.data_ptr()
+    ids.shadow_shape, ids.shadow_tri = sh_shape.data_ptr(), sh_tri.data_ptr()
+    torch.cuda.synchronize()
+
+    def window_samples(w):
+        x0, y0, ww, wh = w
+        j, i, k = torch.meshgrid(torch.arange(y0, y0 + wh, device="cuda"), torch.arange(x0, x0 + ww, device="cuda"),
+                                 torch.arange(spp, device="cuda"), indexing="ij")
+        return ((i + j * W) * spp + k).reshape(-1)
+
+    whole_pixels = {}
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        a = dev.render_args(n, mode=mode, tile=(tile, tile))
+        st = dev.render_device(a, fb.data_ptr(), ids=ids, want_stats=True)
+        assert st.primary_rays == W * H * spp
+        assert st.kernel_launches[rt.KERNEL_CLASSES.index("resolve")] >= 30  # 16 Mi samples per batch
+        image = fb.cpu().numpy().reshape(H, W, 3)
+        whole_pixels[mode] = (image, st.total_rays())
+        for w, (ref_fb, ref_ids, _) in zip(windows, ref):
+            x0, y0, ww, wh = w
+            s = window_samples(w)
+            got_shape, got_tri = prim_shape[s].cpu().numpy(), prim_tri[s].cpu().numpy()
+            same = (got_shape == ref_ids.primary_shape) & (got_tri == ref_ids.primary_tri)
+            assert same.mean() >= parity.ID_MATCH_MIN, (mode, w, same.mean())
+            sl = (s[:, None] * npl + torch.arange(npl, device="cuda")[None, :]).reshape(-1)
+            got_sh = sh_shape[sl].cpu().numpy().reshape(-1, npl)
+            got_sh_tri = sh_tri[sl].cpu().numpy().reshape(-1, npl)
+            cast = (got_sh != -2) | (ref_ids.shadow_shape != -2)
+            if mode == rt.RT_MODE_FAST:  # stops at the first blocker: hidden or not
+                same_sh = np.where(got_sh >= 0, 1, got_sh) == np.where(ref_ids.shadow_shape >= 0, 1, ref_ids.shadow_shape)
+            else:                        # the closest blocker, as light/point.rs:35
+                same_sh = (got_sh == ref_ids.shadow_shape) & (got_sh_tri == ref_ids.shadow_tri)
+            if cast.any():
+                assert same_sh[cast].mean() >= parity.ID_MATCH_MIN, (mode, w, same_sh[cast].mean())
+            m = parity.image_metrics(image[y0:y0 + wh, x0:x0 + ww], ref_fb)
+            assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, (mode, w, m)
+    assert parity.image_metrics(whole_pixels[0][0], whole_pixels[1][0])["lsb1_fraction"] >= parity.LSB_MATCH_MIN
+    del prim_shape, prim_tri, sh_shape, sh_tri
+
+    # the frame in 8 parts (what 8 GPUs render), gathered end to end and un-tiled
+    a = dev.render_args(n, tile=(tile, tile), part=(0, parts))
+    total, owned, stride = dev.partition_info(a)
+    part_floats = stride * tile * tile * 3
+    gathered = torch.zeros(parts * part_floats, dtype=torch.float32, device="cuda")
+    out = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rays = 0
+    for p in range(parts):
+        a = dev.render_args(n, tile=(tile, tile), part=(p, parts))
+        rays += dev.render_device(a, gathered.data_ptr() + p * part_floats * 4, want_stats=True).total_rays()
+    dev.untile_device(a, gathered.data_ptr(), out.data_ptr())
+    backend.sync()
+    assert np.array_equal(out.cpu().numpy().reshape(H, W, 3), whole_pixels[0][0])
+    assert rays == whole_pixels[0][1]
     dev.close()
 
 
