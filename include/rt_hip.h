@@ -261,6 +261,22 @@ int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const R
                      float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream,
                      RtStats *stats_out);
 
+/* rt_render_device for callers that cannot allocate -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (whose render allocates
+ * its framebuffer and, per hit, its light lists).  The call makes no allocation of any kind, on the
+ * device or through the HIP runtime: the ray queues, hit records, lit table and counters of a batch
+ * are laid out in a static array of RT_STATIC_SCRATCH_BYTES that is part of the library's code
+ * object (every GPU the library runs on holds its own copy from load until the process ends; its
+ * device address is looked up once, in rt_backend_create).  Same pixels as rt_render_device: a frame
+ * larger than the array is rendered in more batches of fewer tiles.  Limits: whole frames only
+ * (part_count <= 1); no statistics, timed_classes is ignored, progress is not called; ONE tile
+ * (tile_w x tile_h x rays per pixel samples, about 240 + 12 x point lights bytes each) must fit the
+ * array, else RT_ERR_INVALID.  All calls on one GPU share that GPU's array, whatever backend they go
+ * through: calls that overlap on one GPU race (frames on one stream, or ordered by events, do not). */
+#define RT_STATIC_SCRATCH_BYTES (64u << 20)
+int rt_render_device_static(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
+                            float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream);
+
 /* Waits for the frames enqueued with RtRenderArgs::timed_classes since the last call and fills
  * kernel_ms / kernel_launches of `out` with their sums (all other fields 0).  Lets a caller keep
  * many frames in flight and still learn how long a kernel took on the device: every event pair

@@ -42,6 +42,7 @@ RT_RENDER_ROW_MAJOR_PIXELS = 2
 RT_RENDER_UNFUSED_SHADOWS = 4
 RT_UPLOAD_REFERENCE_MESH_TREES = 1
 RT_COMM_ID_BYTES = 128
+RT_STATIC_SCRATCH_BYTES = 64 << 20
 RT_K_COUNT = 8
 KERNEL_CLASSES = ("raygen", "trace_closest", "shade", "trace_shadow", "accumulate", "resolve")
 
@@ -269,6 +270,7 @@ def lib() -> C.CDLL:
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), C.POINTER(RtStats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp, C.POINTER(RtStats)]
     L.rt_scene_upload_with.argtypes = [vp, C.POINTER(RtScene), C.POINTER(RtUploadOptions), C.POINTER(vp)]
+    L.rt_render_device_static.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtRayIds), vp]
     L.rt_render_async.argtypes = [vp, vp, C.POINTER(RtRenderArgs), vp]
     L.rt_backend_sync.argtypes = [vp]
     L.rt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -676,6 +678,11 @@ class DeviceScene:
             )
         )
         return stats
+
+    def render_device_static(self, args: RtRenderArgs, fb_dev_ptr: int, stream: int = 0, ids: Optional[RtRayIds] = None) -> None:
+        """rt_render_device_static: the same frame with all work memory in the library's static device array."""
+        _check(lib().rt_render_device_static(self.backend.handle, self._h, C.byref(args), fb_dev_ptr,
+                                             C.byref(ids) if ids is not None else None, stream or None))
 
     def untile_device(self, args: RtRenderArgs, gathered_dev_ptr: int, fb_dev_ptr: int, stream: int = 0,
                       part_pitch_floats: int = 0) -> None:

@@ -45,6 +45,13 @@
 #define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
 #define RT_PACKET_BLOCK 64
 
+// Work memory of rt_render_device_static: one array per device the library runs on, part of the
+// code object, so it exists from the moment the library is loaded on a device until the process ends
+// and no call has to allocate it.  Host code never uses this name as an address (on the host it is
+// only a handle for hipGetSymbolAddress); rt_backend_create asks the runtime for the array's device
+// address once per backend, with the backend's device current, and keeps it in RtBackend::scratch.
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 // ------------------------------------------------------------------ device helpers
@@ -496,46 +503,82 @@ int alloc_into(std::vector<void *> &owner, T **out, size_t count) {
     return RT_OK;
 }
 
+// Points the arrays of `Q` at memory for `capacity` samples and `n_point_lights` lights, taken piece by
+// piece from `take(bytes)` (nullptr = out of memory).  Every array starts on a 256-byte boundary of
+// whatever `take` hands out.
+template <class Take>
+bool assign_buffers(RtBuffers &Q, uint32_t capacity, uint32_t n_point_lights, Take take) {
+    std::memset(&Q, 0, sizeof(Q));
+    const size_t cap = std::max<uint32_t>(capacity, 1);
+    const size_t npl = std::max<uint32_t>(n_point_lights, 1);
+    bool ok = true;
+    auto get = [&](auto **out, size_t count) {
+        typedef std::remove_reference_t<decltype(**out)> T;
+        *out = ok ? (T *)take(count * sizeof(T)) : nullptr;
+        ok = ok && *out != nullptr;
+    };
+    for (int w = 0; w < 2; ++w) {
+        for (int k = 0; k < 3; ++k) {
+            get(&Q.q_o[w][k], cap);
+            get(&Q.q_d[w][k], cap);
+        }
+        get(&Q.q_sample[w], cap);
+        get(&Q.q_org_shape[w], cap);
+        get(&Q.q_org_tri[w], cap);
+        get(&Q.q_self_t[w], cap);
+    }
+    get(&Q.h_t, cap);
+    get(&Q.h_shape, cap);
+    get(&Q.h_tri, cap);
+    for (int k = 0; k < 3; ++k) {
+        get(&Q.l_p[k], cap);
+        get(&Q.l_n[k], cap);
+        get(&Q.l_d[k], cap);
+    }
+    get(&Q.l_shape, cap);
+    get(&Q.l_tri, cap);
+    get(&Q.l_self, cap);
+    get(&Q.occ_shape, cap * npl);
+    get(&Q.occ_tri, cap * npl);
+    get(&Q.occ_t, cap * npl);
+    get(&Q.color, cap * 3);
+    // the counters and, behind them, the per-chunk lit counts: one memset clears both
+    get(&Q.counters, (size_t)RT_CNT_SIZE + cap / RT_LIT_CHUNK + 1);
+    get(&Q.lit_list, cap);
+    if (!ok) return false;
+    Q.block_counts = Q.counters + RT_CNT_SIZE;
+    Q.capacity = capacity;
+    return true;
+}
+
+// Device bytes assign_buffers takes for a batch of `capacity` samples, every array padded to 256 bytes.
+size_t buffer_bytes(uint32_t capacity, uint32_t n_point_lights) {
+    size_t total = 0;
+    RtBuffers Q;
+    assign_buffers(Q, capacity, n_point_lights, [&](size_t bytes) {
+        total += (bytes + 255u) & ~(size_t)255u;
+        return (void *)(uintptr_t)256;  // any non-null value: nothing is dereferenced
+    });
+    return total;
+}
+
 int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
     if (be->buf_capacity >= capacity && be->buf_point_lights >= n_point_lights) return RT_OK;
     free_all(be->buf_allocs);
     be->buf_capacity = 0;
-    RtBuffers &Q = be->buf;
-    std::memset(&Q, 0, sizeof(Q));
-    const size_t cap = capacity;
-    const size_t npl = std::max<uint32_t>(n_point_lights, 1);
-    int rc;
-    for (int w = 0; w < 2; ++w) {
-        for (int k = 0; k < 3; ++k) {
-            if ((rc = alloc_into(be->buf_allocs, &Q.q_o[w][k], cap))) return rc;
-            if ((rc = alloc_into(be->buf_allocs, &Q.q_d[w][k], cap))) return rc;
-        }
-        if ((rc = alloc_into(be->buf_allocs, &Q.q_sample[w], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.q_org_shape[w], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.q_org_tri[w], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.q_self_t[w], cap))) return rc;
+    hipError_t err = hipSuccess;
+    const bool ok = assign_buffers(be->buf, capacity, n_point_lights, [&](size_t bytes) -> void * {
+        void *p = nullptr;
+        err = hipMalloc(&p, std::max<size_t>(bytes, 1));
+        if (err != hipSuccess) return nullptr;
+        be->buf_allocs.push_back(p);
+        return p;
+    });
+    if (!ok) {
+        free_all(be->buf_allocs);
+        return rt::set_error(RT_ERR_DEVICE, std::string("hipMalloc of the batch buffers: ") + hipGetErrorString(err));
     }
-    if ((rc = alloc_into(be->buf_allocs, &Q.h_t, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.h_shape, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.h_tri, cap))) return rc;
-    for (int k = 0; k < 3; ++k) {
-        if ((rc = alloc_into(be->buf_allocs, &Q.l_p[k], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.l_n[k], cap))) return rc;
-        if ((rc = alloc_into(be->buf_allocs, &Q.l_d[k], cap))) return rc;
-    }
-    if ((rc = alloc_into(be->buf_allocs, &Q.l_shape, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.l_tri, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.l_self, cap))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.occ_shape, cap * npl))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.occ_tri, cap * npl))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.occ_t, cap * npl))) return rc;
-    if ((rc = alloc_into(be->buf_allocs, &Q.color, cap * 3))) return rc;
-    // the counters and, behind them, the per-chunk lit counts: one memset clears both
-    if ((rc = alloc_into(be->buf_allocs, &Q.counters, (size_t)RT_CNT_SIZE + cap / RT_LIT_CHUNK + 1))) return rc;
-    Q.block_counts = Q.counters + RT_CNT_SIZE;
-    if ((rc = alloc_into(be->buf_allocs, &Q.lit_list, cap))) return rc;
-    Q.overflow = be->sticky;
-    Q.capacity = capacity;
+    be->buf.overflow = be->sticky;
     be->buf_capacity = capacity;
     be->buf_point_lights = n_point_lights;
     return RT_OK;
@@ -657,7 +700,7 @@ bool rt::is_pinned_host(const void *p) {
 }
 
 int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
-                     hipStream_t stream, RtStats *stats, bool blocking) {
+                     hipStream_t stream, RtStats *stats, bool blocking, bool static_memory) {
     if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
     if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
     if (args->antialias_method < RT_AA_NORMAL || args->antialias_method > RT_AA_RANDOM)
@@ -684,9 +727,11 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     if (!stream) stream = be->stream;
     be->last_stream = stream;
 
-    // ---- tile list (cached per partition)
+    // ---- tile list (cached per partition); a whole frame in static memory needs none: slot k is tile k
+    if (static_memory && (parts > 1 || stats != nullptr))
+        return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames (part_count <= 1) and no statistics");
     const uint32_t key[6] = {W, H, tw, th, args->part_index, parts | (args->part0_weight << 24)};
-    if (std::memcmp(key, be->tile_key, sizeof(key)) != 0 || !be->tile_list) {
+    if (!static_memory && (std::memcmp(key, be->tile_key, sizeof(key)) != 0 || !be->tile_list)) {
         owned_tiles(tiles_x, tiles_y, args->part_index, parts, args->part0_weight, be->tile_list_host);
         if (be->tile_list) (void)hipFree(be->tile_list);
         be->tile_list = nullptr;
@@ -696,16 +741,41 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                              hipMemcpyHostToDevice));
         std::memcpy(be->tile_key, key, sizeof(key));
     }
-    const uint32_t n_slots = (uint32_t)be->tile_list_host.size();
+    const uint32_t n_slots = static_memory ? tiles_x * tiles_y : (uint32_t)be->tile_list_host.size();
 
     // ---- batch size
     const uint64_t max_batch = args->batch_samples ? args->batch_samples : (16ull << 20);
-    const uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / tile_samples);
+    uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / tile_samples);
+    RtBuffers carved;
+    if (static_memory) {
+        // as many tiles as the device's static array holds; the arrays are laid out in it afresh on every call
+        if (!be->scratch) return rt::set_error(RT_ERR_DEVICE, "the static work memory of this device is not available");
+        const size_t per_tile = buffer_bytes((uint32_t)tile_samples, ds->n_point_lights);
+        uint32_t fit = (uint32_t)std::min<uint64_t>(slots_per_batch, (uint64_t)RT_STATIC_SCRATCH_BYTES / std::max<size_t>(per_tile, 1) + 1);
+        while (fit > 0 && buffer_bytes((uint32_t)(fit * tile_samples), ds->n_point_lights) > (size_t)RT_STATIC_SCRATCH_BYTES) --fit;
+        if (fit == 0)
+            return rt::set_error(RT_ERR_INVALID, "one tile of " + std::to_string(tile_samples) + " samples with " +
+                                                     std::to_string(ds->n_point_lights) + " point lights needs " + std::to_string(per_tile) +
+                                                     " bytes of work memory; the static array holds " +
+                                                     std::to_string((size_t)RT_STATIC_SCRATCH_BYTES) + ": use smaller tiles or fewer rays per pixel");
+        slots_per_batch = fit;
+    }
     const uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
     const uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
-    int rc = ensure_buffers(be, capacity, ds->n_point_lights);
-    if (rc) return rc;
-    const RtBuffers Q = be->buf;
+    int rc = RT_OK;
+    if (static_memory) {
+        size_t used = 0;
+        unsigned char *base = be->scratch;
+        assign_buffers(carved, capacity, ds->n_point_lights, [&](size_t bytes) -> void * {
+            void *p = base + used;
+            used += (bytes + 255u) & ~(size_t)255u;
+            return p;
+        });
+        carved.overflow = be->sticky;
+    } else if ((rc = ensure_buffers(be, capacity, ds->n_point_lights))) {
+        return rc;
+    }
+    const RtBuffers Q = static_memory ? carved : be->buf;
     const RtSceneView &S = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view : ds->view_fast;
 
     RtIdOut io{};
@@ -719,7 +789,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     }
 
     Timing tm;
-    tm.on = stats != nullptr || args->timed_classes != 0;
+    tm.on = !static_memory && (stats != nullptr || args->timed_classes != 0);  // an event pair is an allocation
     if (!stats) tm.mask = args->timed_classes;
     tm.stream = stream;
     struct FrameEvents {  // destroyed on every return path
@@ -756,7 +826,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
         RtBatch B{};
-        B.tile_list = be->tile_list;
+        B.tile_list = static_memory ? nullptr : be->tile_list;
         B.slot0 = slot0;
         B.n_pixels = slots * tw * th;
         B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x;
@@ -912,6 +982,8 @@ extern "C" int rt_backend_create(int device_ordinal, RtBackend **backend_out) {
     if (e == hipSuccess) e = hipMalloc((void **)&be->sticky, 256);
     if (e == hipSuccess) e = hipMemset(be->sticky, 0, 256);
     if (e == hipSuccess) e = hipHostMalloc((void **)&be->sticky_host, 64, hipHostMallocDefault);
+    // the device address of this device's copy of the static work array (this device is current)
+    if (e == hipSuccess) e = hipGetSymbolAddress((void **)&be->scratch, HIP_SYMBOL(scratch));
     if (e != hipSuccess) {
         rt_backend_destroy(be);
         return rt::set_error(RT_ERR_DEVICE, std::string("backend set-up: ") + hipGetErrorString(e));
@@ -1068,7 +1140,12 @@ extern "C" uint32_t rt_scene_point_light_count(const RtDeviceScene *ds) { return
 
 extern "C" int rt_render_device(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_dev,
                                 const RtRayIds *ids_dev, void *hip_stream, RtStats *stats_out) {
-    return rt::render_frame(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, stats_out, false);
+    return rt::render_frame(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, stats_out, false, false);
+}
+
+extern "C" int rt_render_device_static(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_dev,
+                                       const RtRayIds *ids_dev, void *hip_stream) {
+    return rt::render_frame(be, ds, args, fb_rgb_dev, ids_dev, (hipStream_t)hip_stream, nullptr, false, true);
 }
 
 extern "C" int rt_render_async(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_pinned) {
@@ -1079,7 +1156,7 @@ extern "C" int rt_render_async(RtBackend *be, const RtDeviceScene *ds, const RtR
         return rt::set_error(RT_ERR_INVALID, "rt_render_async needs page-locked host memory (rt_host_alloc)");
     const size_t fb_floats = (size_t)ds->width * ds->height * 3;
     if (int grown = rt::ensure_device_fb(be, fb_floats)) return grown;
-    if (int rc = rt::render_frame(be, ds, args, be->fb, nullptr, be->stream, nullptr, false)) return rc;
+    if (int rc = rt::render_frame(be, ds, args, be->fb, nullptr, be->stream, nullptr, false, false)) return rc;
     RT_HIP(hipMemcpyAsync(fb_rgb_pinned, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream));
     return RT_OK;
 }
@@ -1134,7 +1211,7 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
     }
     // The kernels are only enqueued here (statistics and a progress callback excepted, which make
     // render_frame wait); the copy of the frame follows on the same stream, and ONE wait ends the call.
-    int rc = rt::render_frame(be, ds, args, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out, true);
+    int rc = rt::render_frame(be, ds, args, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out, true, false);
     if (rc) {
         cleanup();
         return rc;

@@ -40,6 +40,8 @@ struct RtBackend {
     // and the page-locked host word it is copied to when the host looks
     uint32_t *sticky = nullptr;
     uint32_t *sticky_host = nullptr;
+    // device address of this device's static work array (rt_render_device_static), from hipGetSymbolAddress
+    unsigned char *scratch = nullptr;
     // tile list of the last partition
     int32_t *tile_list = nullptr;
     std::vector<int32_t> tile_list_host;
@@ -73,8 +75,10 @@ namespace rt {
 // the call waits for the frame and checks the overflow word.  `blocking`: the caller is going to wait
 // for the frame anyway (and calls finish_stream itself), so the progress callback may be served,
 // which takes a wait per batch.
+// `static_memory`: the batch buffers are laid out in the device's static work array (RtBackend::scratch)
+// and the call makes no allocation of any kind: whole frames only, no statistics, no timing events.
 int render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
-                 hipStream_t stream, RtStats *stats, bool blocking);
+                 hipStream_t stream, RtStats *stats, bool blocking, bool static_memory);
 
 // Waits for `stream` and turns a set overflow word into an error (clearing it).
 int finish_stream(RtBackend *be, hipStream_t stream);

@@ -208,7 +208,7 @@ void worker_loop(RtMulti *m, uint32_t k) {
         lock.unlock();
         RtBackend *be = m->backends[k];
         int rc = hipSetDevice(be->device) == hipSuccess ? RT_OK : rt::set_error(RT_ERR_DEVICE, "hipSetDevice failed");
-        if (!rc) rc = rt::render_frame(be, m->scenes[k], &w.args, w.dst, nullptr, be->stream, w.stats, false);
+        if (!rc) rc = rt::render_frame(be, m->scenes[k], &w.args, w.dst, nullptr, be->stream, w.stats, false, false);
         if (!rc && m->part_done[k] && hipEventRecord(m->part_done[k], be->stream) != hipSuccess)
             rc = rt::set_error(RT_ERR_DEVICE, "hipEventRecord failed");
         lock.lock();

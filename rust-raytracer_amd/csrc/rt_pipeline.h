@@ -92,7 +92,7 @@ enum {
 // Which pixels a batch covers.  Local pixel lp of the batch lies in tile slot
 // slot0 + lp / (tile_w*tile_h); tile_list maps a slot to the row-major tile index.
 struct RtBatch {
-    const int32_t *tile_list;
+    const int32_t *tile_list;  // null: every tile is owned, slot k is tile k
     uint32_t slot0;       // first tile slot of this batch
     uint32_t n_pixels;    // local pixels (tile slots x tile_w x tile_h)
     uint32_t tile_w, tile_h, tiles_x;
@@ -131,7 +131,7 @@ struct RtIdOut {  // RtRayIds, device pointers (any may be null)
 
 RT_HD bool batch_pixel(const RtBatch &B, uint32_t lp, uint32_t &i, uint32_t &j) {
     const uint32_t in_batch = rt_div(lp, B.div_tile_px), r = lp - in_batch * B.div_tile_px.d;
-    const uint32_t tile = (uint32_t)B.tile_list[B.slot0 + in_batch];
+    const uint32_t tile = B.tile_list ? (uint32_t)B.tile_list[B.slot0 + in_batch] : B.slot0 + in_batch;
     const uint32_t bshift = B.blk_w_log2 + B.blk_h_log2;
     const uint32_t blk = r >> bshift, in_blk = r & ((1u << bshift) - 1u);
     const uint32_t blk_y = rt_div(blk, B.div_blocks_row), blk_x = blk - blk_y * B.div_blocks_row.d;
