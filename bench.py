@@ -11,9 +11,10 @@ A step is one render of the whole frame with the scene already resident in HBM, 
 frame in page-locked host memory.  One GPU: rt_render_async on FLIGHTS backends in turn, so the copy
 of frame k over the bus overlaps the kernels of frame k+1.  N > 1: the frame is cut into interleaved
 tiles, rank r renders the tiles of part r into a compact device buffer, the library's RCCL gather
-(rt_comm_gather: grouped ncclSend / ncclRecv) brings the buffers to rank 0, a kernel there restores
-the image layout and the frame is copied to host memory; total work is fixed, so scaling is
-"strong".  Rank 0 prints one JSON line.
+(rt_comm_gather: grouped ncclSend / ncclRecv) brings the buffers of a group of frames to that group's
+root, a kernel there restores the image layout and the frames are copied to host memory; the root
+rotates over the ranks from group to group.  Total work is fixed, so scaling is "strong".  Rank 0
+prints one JSON line.
 """
 from __future__ import annotations
 
@@ -204,10 +205,9 @@ def main():
     upload_s = (time.perf_counter() - t_up) / FLIGHTS
     dev = devs[0]
     mode = rt.RT_MODE_FAST if args.mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
-    # Rank 0 also receives the other ranks' tiles, restores the image layout of every frame and sends it
-    # to the host: with 1/8 frames that is a tenth of its time even when the gather is a local copy,
-    # so from five GPUs on it takes 6/8 of the share the others get.
-    part0_weight = int(os.environ.get("RT_BENCH_PART0_WEIGHT", "6" if many_parts else "0"))
+    # Equal parts: the root of the gather rotates over the ranks (see flush below), so no rank has more to
+    # do than another.  (RtRenderArgs.part0_weight is there for a caller that keeps one fixed root.)
+    part0_weight = int(os.environ.get("RT_BENCH_PART0_WEIGHT", "0"))
     rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight,
                             flags=args.render_flags)
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
@@ -248,48 +248,54 @@ def main():
                 be.sync()
     else:
         # GROUP consecutive frames are gathered together: every rank renders its part of each into one
-        # buffer, ONE gather brings all of them to rank 0, and rank 0 restores the image layout frame
-        # by frame on a side stream and sends each frame to page-locked host memory.  Two groups
-        # alternate, so the gather, un-tiling and copies of one overlap the renders of the other.
+        # buffer, ONE gather brings all of them to the group's root, and the root restores the image
+        # layout frame by frame on a side stream and sends each frame to page-locked host memory.  Two
+        # groups alternate, so the gather, un-tiling and copies of one overlap the renders of the other.
         # Measured on one MI355X with a one-rank communicator (the gather degenerates to a local copy,
         # so this is a lower bound), per 1/8 frame: render alone 0.169 ms; with a gather and an un-tile
         # per frame 0.245 ms; per group of 8 frames 0.191 ms, of 16 frames 0.183 ms.
+        # The ROOT ROTATES: group k is gathered to rank k mod N.  Receiving, un-tiling and above all the
+        # copy to the host (12 MB per frame: one GPU's PCIe link carries about 4000 such frames a second,
+        # eight GPUs render 6000) are then shared by all GPUs and their links, every rank does the same
+        # work, and the parts can be equal.
         GROUP = 2 * FLIGHTS
         part_floats = stride * tile_floats
         part = [torch.zeros(GROUP * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
-        root = rank == 0
-        gathered = [torch.zeros(world * GROUP * part_floats, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
-        fb = [torch.zeros(fb_floats, dtype=torch.float32, device="cuda") if root else None for _ in range(2)]
-        host_fb = [torch.zeros(fb_floats, dtype=torch.float32).pin_memory() if root else None for _ in range(2)]
-        delivered = host_fb[0].numpy().reshape(H, W, 3) if root else None
+        gathered = [torch.zeros(world * GROUP * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        fb = [torch.zeros(fb_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        host_fb = [torch.zeros(fb_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
         joiner = torch.cuda.Stream()     # waits for the frames of a group, then issues their gather
-        side = torch.cuda.Stream()       # rank 0: waits for a gather, restores the image layout, copies to the host
+        side = torch.cuda.Stream()       # the root: waits for a gather, restores the image layout, copies to the host
         sent = [None, None]              # event: the gather that read part[g] / wrote gathered[g] is done
         untiled = [None, None]           # event: gathered[g] has been consumed
-        last_delivered = [None]          # rank 0: the host buffer that holds the newest frame
+        last_delivered = [None]          # the host buffer that holds the newest frame this rank was root for
+        groups_done = [0]
         if not staged:
             # the library's own RCCL communicator: rank 0 makes the id, the launcher's process group carries it
-            ids = [rt.Comm.make_id() if root else None]
+            ids = [rt.Comm.make_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             comm = rt.Comm(backends[0], ids[0], rank, world)
 
         def flush(g, count):
-            """Gathers the first `count` frames of group g and, on rank 0, un-tiles them and copies them out."""
+            """Gathers the first `count` frames of group g to the group's root, which un-tiles them and copies them out."""
+            root_rank = groups_done[0] % world
+            groups_done[0] += 1
+            root = rank == root_rank
             for b in range(min(count, FLIGHTS)):
                 joiner.wait_stream(streams[b])
             mine = part[g][: count * part_floats]
             with torch.cuda.stream(joiner):
+                if untiled[g] is not None:
+                    joiner.wait_event(untiled[g])
                 if staged:  # rehearsal on one GPU: through host memory
                     cpu = mine.cpu()
                     bufs = [torch.empty_like(cpu) for _ in range(world)] if root else None
-                    dist.gather(cpu, bufs, dst=0)
+                    dist.gather(cpu, bufs, dst=root_rank)
                     if root:
                         gathered[g][: world * count * part_floats].copy_(torch.cat(bufs))
                 else:
-                    if untiled[g] is not None:
-                        joiner.wait_event(untiled[g])
                     # rank r's frames land at r * count blocks: [rank][frame][block]
-                    comm.gather(mine.data_ptr(), count * part_floats, gathered[g].data_ptr() if root else 0, stream=joiner.cuda_stream)
+                    comm.gather(mine.data_ptr(), count * part_floats, gathered[g].data_ptr(), root=root_rank, stream=joiner.cuda_stream)
                 sent[g] = joiner.record_event()
             if root:
                 with torch.cuda.stream(side):
@@ -384,18 +390,28 @@ def main():
         solo_launches = int(t.kernel_launches[dom])
 
     # Outside the timed region: the gathered frame must be bit-identical with the same frame rendered
-    # whole on rank 0 (static tile map, ordered per-pixel sums).
+    # whole (static tile map, ordered per-pixel sums).  Every rank that was a root checks the newest
+    # frame it delivered against its own single-GPU render of the frame.
     frame_check = None
     if multi and world == 1:
         frame_check = "not applicable: a single part is rendered in image layout, not tile by tile"
-    elif multi and rank == 0:
-        whole = torch.zeros(fb_floats, dtype=torch.float32, device="cuda")
-        dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile)), whole.data_ptr(), stream=streams[0].cuda_stream)
-        torch.cuda.synchronize()
-        last = last_delivered[0]
-        if not torch.equal(whole.cpu(), last):
-            raise SystemExit(f"gathered frame differs from the single-GPU frame in {int((whole.cpu() != last).sum())} values")
-        frame_check = "gathered frame (in host memory) bit-identical with rank 0's single-GPU render"
+    elif multi:
+        bad = 0
+        if last_delivered[0] is not None:
+            whole = torch.zeros(fb_floats, dtype=torch.float32, device="cuda")
+            dev.render_device(dev.render_args(n, mode=mode, tile=(tile, tile), flags=args.render_flags), whole.data_ptr(),
+                              stream=streams[0].cuda_stream)
+            backends[0].sync()
+            torch.cuda.synchronize()
+            bad = int((whole.cpu() != last_delivered[0]).sum())
+        checked = torch.tensor([bad, 1 if last_delivered[0] is not None else 0], dtype=torch.int64)
+        if not staged:
+            checked = checked.cuda()
+        dist.all_reduce(checked, op=dist.ReduceOp.SUM)
+        if int(checked[0]) != 0:
+            raise SystemExit(f"gathered frames differ from the single-GPU frame in {int(checked[0])} values")
+        frame_check = (f"newest gathered frame in host memory bit-identical with a single-GPU render of the frame, "
+                       f"on each of the {int(checked[1])} ranks that served as root")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor([rays_per_frame_local * args.steps], dtype=torch.float64, device="cuda")
@@ -482,7 +498,8 @@ def main():
                        "rccl_ranks": dist.get_world_size() if multi else 1,
                        "gather": ("none (one GPU)" if not multi else
                                   "host memory over gloo (one-GPU rehearsal)" if staged else
-                                  "rt_comm_gather: grouped ncclSend / ncclRecv on the library's RCCL communicator"),
+                                  "rt_comm_gather: grouped ncclSend / ncclRecv on the library's RCCL communicator, "
+                                  "root rotating over the ranks from one group of frames to the next"),
                        "render_flags": args.render_flags,
                        "scene_upload_ms": upload_s * 1e3,
                        "kernel_split_from": "last warm-up frame (fully instrumented, every kernel alone on the GPU)"},

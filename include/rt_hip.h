@@ -335,16 +335,20 @@ int rt_render_multi(RtMulti *multi, const RtRenderArgs *args, float *fb_rgb, RtS
 /* The same gather for a launcher with ONE PROCESS PER GPU (MPI, torch.distributed): rank 0 makes
  * an id and hands it to the other ranks by whatever means the launcher has, every rank creates its
  * end of the communicator (ncclCommInitRank) on its backend's device, and rt_comm_gather enqueues
- * on `hip_stream`: this rank's `floats` floats at `part_dev` go to rank 0, which receives rank r's
- * at gathered_dev + r * floats (gathered_dev is ignored on the other ranks).  Collective: every
- * rank must call it, with the same `floats`. */
+ * on `hip_stream`: this rank's `floats` floats at `part_dev` go to rank `root`, which receives
+ * rank r's at gathered_dev + r * floats (gathered_dev is ignored on the other ranks).  Collective:
+ * every rank must call it, with the same `floats` and `root`.  A caller that renders a stream of
+ * frames can name a different root for every frame (or group of frames): receiving, restoring the
+ * image layout and the copy to the host over that GPU's own PCIe link are then shared by all GPUs
+ * instead of falling on one. */
 #define RT_COMM_ID_BYTES 128
 typedef struct RtComm RtComm;
 int rt_comm_id(uint8_t id_out[RT_COMM_ID_BYTES]);
 int rt_comm_create(RtBackend *backend, const uint8_t id[RT_COMM_ID_BYTES], uint32_t rank, uint32_t world,
                    RtComm **comm_out);
 void rt_comm_destroy(RtComm *comm);
-int rt_comm_gather(RtComm *comm, const float *part_dev, size_t floats, float *gathered_dev, void *hip_stream);
+int rt_comm_gather(RtComm *comm, const float *part_dev, size_t floats, float *gathered_dev, uint32_t root,
+                   void *hip_stream);
 
 /* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
  * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).

@@ -284,7 +284,7 @@ def lib() -> C.CDLL:
     L.rt_comm_create.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rt_comm_destroy.argtypes = [vp]
     L.rt_comm_destroy.restype = None
-    L.rt_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    L.rt_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp]
     L.rt_collect_timings.argtypes = [vp, C.POINTER(RtStats)]
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
     L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
@@ -381,8 +381,8 @@ class Comm:
         self.rank, self.world = rank, world
         _check(lib().rt_comm_create(backend.handle, buf, rank, world, C.byref(self._h)))
 
-    def gather(self, part_dev_ptr: int, floats: int, gathered_dev_ptr: int, stream: int = 0) -> None:
-        _check(lib().rt_comm_gather(self._h, part_dev_ptr, floats, gathered_dev_ptr or None, stream or None))
+    def gather(self, part_dev_ptr: int, floats: int, gathered_dev_ptr: int, root: int = 0, stream: int = 0) -> None:
+        _check(lib().rt_comm_gather(self._h, part_dev_ptr, floats, gathered_dev_ptr or None, root, stream or None))
 
     def close(self) -> None:
         if self._h:

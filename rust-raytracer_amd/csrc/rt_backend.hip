@@ -32,11 +32,21 @@
 // handful of values that get spilled for it -- as long as the spills stay out of the loops:
 //   packets   8 waves (64 VGPRs, 36..48 B of scratch in the scene-level primitive code): bunny frame
 //             camera rays 0.326 -> 0.312 ms, shadow rays 0.794 -> 0.736 ms; 7 waves lies in between
-//   shade     4 waves (127 VGPRs, no scratch; 131 without the hint, which is 3 waves): 0.342 -> 0.310 ms;
-//             5 waves spill 108 B inside the f64 code: 0.49 ms
+//   shade     behind camera rays (k_shade<true>, no loop, no queue code): 6 waves (79 VGPRs, 12 B of scratch),
+//             bunny frame 0.318 -> 0.253 ms (5 waves: 0.267); behind mirror bounces (k_shade<false>): 4 waves
+//             (125 VGPRs, no scratch; 5 waves spill 108 B inside the f64 code)
+//   shadow rays + light sums in one kernel: 7 waves (72 VGPRs); at 8 the f64 light sums spill 64 B and the
+//             frame is 2 % slower than with separate kernels, at 7 it is as fast (bunny, 2 lights) or
+//             7 % faster (spheres_1K, 4 lights)
 //   accumulate 8 waves (60 VGPRs, no scratch; 76 without the hint): 0.195 -> 0.183 ms
 #define RT_PACKET_WAVES 8
+#ifndef RT_FUSED_WAVES
+#define RT_FUSED_WAVES 7
+#endif
 #define RT_SHADE_WAVES 4
+#ifndef RT_SHADE_FIRST_WAVES
+#define RT_SHADE_FIRST_WAVES 6
+#endif
 #define RT_ACC_WAVES 8
 
 #ifndef RT_BLOCK
@@ -114,9 +124,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuf
         trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, B, bounce, idx, stk);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES))) k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce, uint32_t n_samples) {
-    const uint32_t count = bounce == 0 ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < count; base += gridDim.x * RT_BLOCK) {
+// FIRST: the stage behind the camera rays (bounce 0), launched with one thread per sample: no loop, no
+// queue to read, and the compiler folds every "bounce == 0 ?" of the stage body.  Otherwise a fixed
+// grid strides over the queue of mirror rays, whose length only the device knows.
+template <bool FIRST>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(FIRST ? RT_SHADE_FIRST_WAVES : RT_SHADE_WAVES, FIRST ? RT_SHADE_FIRST_WAVES : RT_SHADE_WAVES)))
+k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce_arg, uint32_t n_samples) {
+    const int bounce = FIRST ? 0 : bounce_arg;
+    const uint32_t count = FIRST ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
+    const uint32_t stride = FIRST ? 0xffffffffu - RT_BLOCK : gridDim.x * RT_BLOCK;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < count; base += stride) {
         const uint32_t idx = base + threadIdx.x;
         MirrorTmp tmp;
         const int act = idx < count ? shade_classify(S, Q, B, ids, bounce, idx, tmp) : RT_ACT_NONE;
@@ -129,7 +146,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         // distinct chunk among its lit lanes (one add per lane made this kernel 1.7x slower on a frame
         // of mirrors: the lanes of a wave mostly hit the same counter and queue up on it).
         unsigned long long todo = __ballot(act == RT_ACT_LIT);
-        if (bounce == 0) {
+        if (FIRST) {
             if (todo != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(todo));
         } else if (todo != 0ull) {
             const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)Q.q_sample[bounce & 1][idx] / RT_LIT_CHUNK : ~0u;
@@ -141,6 +158,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                 todo &= ~same;
             }
         }
+        if (FIRST) break;
     }
 }
 
@@ -246,7 +264,7 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_FUSED_WAVES, RT_FUSED_WAVES)))
 k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
     const uint32_t count = Q.counters[RT_CNT_LIT];
@@ -870,7 +888,10 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                 hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
             if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_shade, dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
+            if (bounce == 0)
+                hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, 0, n_samples);
+            else
+                hipLaunchKernelGGL((k_shade<false>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
             tm.end();
         }
         if (ds->has_lit) {

@@ -140,17 +140,19 @@ extern "C" void rt_comm_destroy(RtComm *c) {
     delete c;
 }
 
-extern "C" int rt_comm_gather(RtComm *c, const float *part_dev, size_t floats, float *gathered_dev, void *hip_stream) {
+extern "C" int rt_comm_gather(RtComm *c, const float *part_dev, size_t floats, float *gathered_dev, uint32_t root,
+                              void *hip_stream) {
     if (!c || !part_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
-    if (c->rank == 0 && !gathered_dev) return rt::set_error(RT_ERR_INVALID, "rank 0 needs a gather buffer");
+    if (root >= c->world) return rt::set_error(RT_ERR_INVALID, "root out of range");
+    if (c->rank == root && !gathered_dev) return rt::set_error(RT_ERR_INVALID, "the root needs a gather buffer");
     if (floats == 0) return RT_OK;
     const Rccl *api = rccl();
     if (!api) return RT_ERR_DEVICE;
     RT_HIP(hipSetDevice(c->backend->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->backend->stream;
     RT_NCCL(api, api->GroupStart());
-    ncclResult_t r = api->Send(part_dev, floats, ncclFloat, 0, c->comm, stream);
-    if (c->rank == 0)
+    ncclResult_t r = api->Send(part_dev, floats, ncclFloat, (int)root, c->comm, stream);
+    if (c->rank == root)
         for (uint32_t peer = 0; peer < c->world && r == ncclSuccess; ++peer)
             r = api->Recv(gathered_dev + (size_t)peer * floats, floats, ncclFloat, (int)peer, c->comm, stream);
     const ncclResult_t end = api->GroupEnd();

@@ -238,7 +238,7 @@ def test_comm_gather_with_one_rank(rt, backend, scene_path):
     for p in range(parts):
         ap = dev.render_args(2, tile=(tile, tile), part=(p, parts))
         dev.render_device(ap, mine.data_ptr(), stream=st.cuda_stream)
-        comm.gather(mine.data_ptr(), block, gathered.data_ptr() + p * block * 4, stream=st.cuda_stream)
+        comm.gather(mine.data_ptr(), block, gathered.data_ptr() + p * block * 4, root=0, stream=st.cuda_stream)
     dev.untile_device(a3, gathered.data_ptr(), fb.data_ptr(), stream=st.cuda_stream)
     backend.sync()
     torch.cuda.synchronize()

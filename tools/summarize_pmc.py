@@ -36,7 +36,10 @@ def main():
         for (disp, cname), val in per_dispatch.items():
             counters[names[disp]][cname].append(val)
     durations = {}
-    for path in glob.glob(os.path.join(root, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+    # kernel durations: from the trace of the run with one frame in flight if there is one (every kernel
+    # alone on the GPU, as under the counter passes), else from the default run's trace
+    trace_dir = "trace_solo" if os.path.isdir(os.path.join(root, "trace_solo")) else "trace"
+    for path in glob.glob(os.path.join(root, trace_dir, "**", "*_kernel_stats.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
                 durations[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
@@ -94,7 +97,21 @@ def main():
             except Exception:
                 table = {}
             dd = timed[dom]["derived"]
+            cc = timed[dom]["counters"]
+            # a frame = one launch of the resolve kernel (frames of up to 16 Mi samples: one batch)
+            frames = max(summary.get("k_resolve", {}).get("calls", 0), 1)
+            frame_bytes = 0.0
+            launches_per_frame = {}
+            for k, d in timed.items():
+                per_frame = d["calls"] / frames
+                launches_per_frame[k] = per_frame
+                frame_bytes += (d["derived"]["hbm_read_bytes"] + d["derived"]["hbm_write_bytes"]) * per_frame
             table[workload] = {"kernel": dom, "hbm_read_bytes": dd["hbm_read_bytes"], "hbm_write_bytes": dd["hbm_write_bytes"],
+                               "valu_wave_insts": cc.get("SQ_INSTS_VALU"),
+                               "scalar_insts": (cc.get("SQ_INSTS_SALU", 0.0) + cc.get("SQ_INSTS_SMEM", 0.0) + cc.get("SQ_INSTS_BRANCH", 0.0)) or None,
+                               "waves": cc.get("SQ_WAVES"),
+                               "frame_hbm_bytes": frame_bytes, "launches_per_frame": launches_per_frame,
+                               "durations_from": trace_dir,
                                "bytes": dd["hbm_read_bytes"] + dd["hbm_write_bytes"], "avg_us": timed[dom]["avg_us"],
                                "hbm_gbs": (dd["hbm_read_bytes"] + dd["hbm_write_bytes"]) / (timed[dom]["avg_us"] * 1e-6) / 1e9,
                                "l2_hit_rate": dd.get("l2_hit_rate"), "valu_lane_utilisation": dd.get("valu_lane_utilisation"),
