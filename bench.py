@@ -358,9 +358,10 @@ def main():
     dom_name = rt.KERNEL_CLASSES[dom]
     rays_per_frame_local = float(s0.total_rays())
 
-    # a few untimed frames through the path that is timed next (its buffers are touched for the first
-    # time, the copy engines and clocks come up), every flight twice
-    for _ in range(2 * FLIGHTS if not multi else 2 * GROUP):
+    # untimed frames through the path that is timed next: its buffers are touched for the first time,
+    # the runtime grows its pools of signals and command buffers, the copy engines and clocks come up.
+    # Measured: the enqueue cost per frame falls from 1.8 ms to 0.03 ms over the first 24 frames.
+    for _ in range(8 * FLIGHTS if not multi else 4 * GROUP):
         step(False)
     # ---- the timed region: EXACTLY args.steps frames, each delivered to host memory
     elapsed = timed(lambda: step(False), args.steps)
