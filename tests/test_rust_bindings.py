@@ -6,6 +6,10 @@ order, and the constants agree.  The patches for the reference's own crates must
 well-formed unified diffs that touch the files they claim to."""
 import os
 import re
+import shutil
+import subprocess
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SYS_RS = os.path.join(ROOT, "integration", "raytracer-hip", "src", "sys.rs")
@@ -190,3 +194,32 @@ def test_patches_are_well_formed_and_say_what_they_are():
     for f in ("Cargo.toml", "build.rs", "src/sys.rs", "src/lib.rs"):
         head = open(os.path.join(ROOT, "integration", "raytracer-hip", f)).read(600)
         assert "NOT COMPILED" in head, f
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "raytracer-lib")) or shutil.which("patch") is None,
+                    reason="needs the reference's sources and patch(1)")
+def test_patches_apply_to_the_reference_sources(tmp_path):
+    """Both patches apply without fuzz or rejects to a scratch copy of the files they name, and the
+    flattened traits end up with one `flatten` per implementation."""
+    pdir = os.path.join(ROOT, "integration", "patches")
+    work = tmp_path / "ref"
+    for patch in ("raytracer-lib-flatten.patch", "raytracer-cli-backend.patch"):
+        text = open(os.path.join(pdir, patch)).read()
+        for rel in re.findall(r"^--- a/(\S+)", text, flags=re.M):
+            src = os.path.join(REFERENCE, rel)
+            dst = work / rel
+            if os.path.isfile(src) and not dst.exists():
+                dst.parent.mkdir(parents=True, exist_ok=True)
+                shutil.copyfile(src, dst)
+    for patch in ("raytracer-lib-flatten.patch", "raytracer-cli-backend.patch"):
+        r = subprocess.run(["patch", "-p1", "--fuzz=0", "--no-backup-if-mismatch", "-i", os.path.join(pdir, patch)],
+                           cwd=work, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "fuzz" not in r.stdout and ".rej" not in r.stdout, r.stdout
+    shape_trait = (work / "raytracer-lib/src/geometry/mod.rs").read_text()
+    assert "fn flatten(" in shape_trait
+    assert "Backend::Hip" in (work / "raytracer-cli/src/main.rs").read_text()
+    assert '"raytracer-hip"' in (work / "Cargo.toml").read_text()
