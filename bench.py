@@ -10,11 +10,11 @@ HOST MEMORY, which is what the reference's render() returns (render.rs:7-23).
 A step is one render of the whole frame with the scene already resident in HBM, ending with the
 frame in page-locked host memory.  One GPU: rt_render_async on FLIGHTS backends in turn, so the copy
 of frame k over the bus overlaps the kernels of frame k+1.  N > 1: the frame is cut into interleaved
-tiles, rank r renders the tiles of part r into a compact device buffer, the library's RCCL gather
-(rt_comm_gather: grouped ncclSend / ncclRecv) brings the buffers of a group of frames to that group's
-root, a kernel there restores the image layout and the frames are copied to host memory; the root
-rotates over the ranks from group to group.  Total work is fixed, so scaling is "strong".  Rank 0
-prints one JSON line.
+tiles, rank r renders the tiles of part r into a compact device buffer, the library's RCCL exchange
+(rt_comm_gather_frames: grouped ncclSend / ncclRecv) brings the parts of a group of frames to the
+frames' roots -- frame k belongs to rank k mod N -- where a kernel restores the image layout and the
+frame is copied to host memory.  Total work is fixed, so scaling is "strong".  Rank 0 prints one JSON
+line.
 """
 from __future__ import annotations
 
@@ -205,7 +205,7 @@ def main():
     upload_s = (time.perf_counter() - t_up) / FLIGHTS
     dev = devs[0]
     mode = rt.RT_MODE_FAST if args.mode == "fast" else rt.RT_MODE_REFERENCE_ORDER
-    # Equal parts: the root of the gather rotates over the ranks (see flush below), so no rank has more to
+    # Equal parts: the root of the gather rotates over the ranks from frame to frame (see flush below), so no rank has more to
     # do than another.  (RtRenderArgs.part0_weight is there for a caller that keeps one fixed root.)
     part0_weight = int(os.environ.get("RT_BENCH_PART0_WEIGHT", "0"))
     rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight,
@@ -247,29 +247,36 @@ def main():
             for be in backends:
                 be.sync()
     else:
-        # GROUP consecutive frames are gathered together: every rank renders its part of each into one
-        # buffer, ONE gather brings all of them to the group's root, and the root restores the image
-        # layout frame by frame on a side stream and sends each frame to page-locked host memory.  Two
-        # groups alternate, so the gather, un-tiling and copies of one overlap the renders of the other.
-        # Measured on one MI355X with a one-rank communicator (the gather degenerates to a local copy,
-        # so this is a lower bound), per 1/8 frame: render alone 0.169 ms; with a gather and an un-tile
-        # per frame 0.245 ms; per group of 8 frames 0.191 ms, of 16 frames 0.183 ms.
-        # The ROOT ROTATES: group k is gathered to rank k mod N.  Receiving, un-tiling and above all the
-        # copy to the host (12 MB per frame: one GPU's PCIe link carries about 4000 such frames a second,
-        # eight GPUs render 6000) are then shared by all GPUs and their links, every rank does the same
-        # work, and the parts can be equal.
-        GROUP = 2 * FLIGHTS
+        # GROUP consecutive frames are exchanged together, and THE ROOT ROTATES FROM FRAME TO FRAME: frame k
+        # of the run belongs to rank k mod N.  Every rank renders its part of each frame of the group
+        # into one buffer (ordered by root, so that what goes to one root is one message), ONE call of
+        # rt_comm_gather_frames posts a send per (rank, root) pair and the receives, and every rank
+        # restores the image layout of the frames it is root of on a side stream and sends each to
+        # page-locked host memory.  Two groups alternate, so the exchange, un-tiling and copies of one
+        # overlap the renders of the other.
+        # Why groups: measured on one MI355X with a one-rank communicator (the exchange degenerates to a
+        # local copy, so this is a lower bound), per 1/8 frame: render alone 0.169 ms; with a gather and an
+        # un-tile per frame 0.245 ms (the stream hand-overs around a collective stall the pipeline); per
+        # group of 8 frames 0.191 ms.
+        # Why rotating roots: a frame is 12 MB; one GPU's PCIe link carries about 4000 such frames a second
+        # while eight GPUs render 6000.  With the frames dealt round robin, receiving, un-tiling and the
+        # copy home are shared by all GPUs and links, the xGMI links carry tiles both ways, every rank does
+        # the same work, the parts can be equal, and when a run ends each GPU has one frame of the last
+        # group left to send home instead of one GPU all of them.
+        GROUP = 8
+        SLOTS = -(-GROUP // world)       # frames of a group per root, at most
         part_floats = stride * tile_floats
-        part = [torch.zeros(GROUP * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
-        gathered = [torch.zeros(world * GROUP * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        part = [torch.zeros(world * SLOTS * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros(world * SLOTS * part_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
         fb = [torch.zeros(fb_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
         host_fb = [torch.zeros(fb_floats, dtype=torch.float32).pin_memory() for _ in range(2)]
-        joiner = torch.cuda.Stream()     # waits for the frames of a group, then issues their gather
-        side = torch.cuda.Stream()       # the root: waits for a gather, restores the image layout, copies to the host
-        sent = [None, None]              # event: the gather that read part[g] / wrote gathered[g] is done
+        joiner = torch.cuda.Stream()     # waits for the frames of a group, then issues their exchange
+        side = torch.cuda.Stream()       # as a root: waits for the exchange, restores the image layout, copies to the host
+        sent = [None, None]              # event: the exchange that read part[g] / wrote gathered[g] is done
         untiled = [None, None]           # event: gathered[g] has been consumed
-        last_delivered = [None]          # the host buffer that holds the newest frame this rank was root for
-        groups_done = [0]
+        last_delivered = [None]          # the host buffer that holds the newest frame this rank was root of
+        frames_sent = [0]                # frames handed to an exchange so far: the next group's first root follows from it
+        frames_rooted = [0]
         if not staged:
             # the library's own RCCL communicator: rank 0 makes the id, the launcher's process group carries it
             ids = [rt.Comm.make_id() if rank == 0 else None]
@@ -277,45 +284,52 @@ def main():
             comm = rt.Comm(backends[0], ids[0], rank, world)
 
         def flush(g, count):
-            """Gathers the first `count` frames of group g to the group's root, which un-tiles them and copies them out."""
-            root_rank = groups_done[0] % world
-            groups_done[0] += 1
-            root = rank == root_rank
+            """Exchanges the first `count` frames of group g; this rank un-tiles and copies out those it is root of."""
+            first_root = frames_sent[0] % world
+            frames_sent[0] += count
             for b in range(min(count, FLIGHTS)):
                 joiner.wait_stream(streams[b])
-            mine = part[g][: count * part_floats]
             with torch.cuda.stream(joiner):
                 if untiled[g] is not None:
                     joiner.wait_event(untiled[g])
-                if staged:  # rehearsal on one GPU: through host memory
-                    cpu = mine.cpu()
-                    bufs = [torch.empty_like(cpu) for _ in range(world)] if root else None
-                    dist.gather(cpu, bufs, dst=root_rank)
-                    if root:
-                        gathered[g][: world * count * part_floats].copy_(torch.cat(bufs))
+                if staged:  # rehearsal on one GPU: the same blocks through host memory, one gather per root
+                    for p in range(min(count, world)):
+                        root_rank = (first_root + p) % world
+                        k = -(-(count - p) // world)
+                        cpu = part[g][p * SLOTS * part_floats: (p * SLOTS + k) * part_floats].cpu()
+                        bufs = [torch.empty_like(cpu) for _ in range(world)] if rank == root_rank else None
+                        dist.gather(cpu, bufs, dst=root_rank)
+                        if rank == root_rank:
+                            for r in range(world):
+                                gathered[g][r * SLOTS * part_floats: (r * SLOTS + k) * part_floats].copy_(bufs[r])
                 else:
-                    # rank r's frames land at r * count blocks: [rank][frame][block]
-                    comm.gather(mine.data_ptr(), count * part_floats, gathered[g].data_ptr(), root=root_rank, stream=joiner.cuda_stream)
+                    comm.gather_frames(part[g].data_ptr(), part_floats, count, first_root, SLOTS, gathered[g].data_ptr(),
+                                       stream=joiner.cuda_stream)
                 sent[g] = joiner.record_event()
-            if root:
+            mine = [f for f in range(count) if rt.Comm.frame_blocks(world, SLOTS, f, first_root)[0] == rank]
+            if mine:
                 with torch.cuda.stream(side):
                     side.wait_event(sent[g])
-                    # frame f starts at f blocks, the ranks lie count blocks apart
-                    for f in range(count):
-                        dev.untile_device(rargs, gathered[g].data_ptr() + f * part_floats * 4, fb[f & 1].data_ptr(),
-                                          stream=side.cuda_stream, part_pitch_floats=count * part_floats)
-                        host_fb[f & 1].copy_(fb[f & 1], non_blocking=True)
-                    last_delivered[0] = host_fb[(count - 1) & 1]
+                    for f in mine:
+                        slot = rt.Comm.frame_blocks(world, SLOTS, f, first_root)[2]
+                        o = frames_rooted[0] & 1
+                        frames_rooted[0] += 1
+                        # rank r's part of the frame lies at block r * SLOTS + slot
+                        dev.untile_device(rargs, gathered[g].data_ptr() + slot * part_floats * 4, fb[o].data_ptr(),
+                                          stream=side.cuda_stream, part_pitch_floats=SLOTS * part_floats)
+                        host_fb[o].copy_(fb[o], non_blocking=True)
+                        last_delivered[0] = host_fb[o]
                     untiled[g] = side.record_event()
 
         def step(want_stats):
             k = counter[0]
             counter[0] += 1
             g, f, b = (k // GROUP) % 2, k % GROUP, k % FLIGHTS
+            block = rt.Comm.frame_blocks(world, SLOTS, f)[1]
             with torch.cuda.stream(streams[b]):
                 if sent[g] is not None:
-                    streams[b].wait_event(sent[g])  # the gather of two groups ago has released part[g]
-                st = devs[b].render_device(rargs, part[g].data_ptr() + f * part_floats * 4, stream=streams[b].cuda_stream,
+                    streams[b].wait_event(sent[g])  # the exchange of two groups ago has released part[g]
+                st = devs[b].render_device(rargs, part[g].data_ptr() + block * part_floats * 4, stream=streams[b].cuda_stream,
                                            want_stats=want_stats)
             if f == GROUP - 1:
                 flush(g, GROUP)
@@ -503,8 +517,8 @@ def main():
                        "rccl_ranks": dist.get_world_size() if multi else 1,
                        "gather": ("none (one GPU)" if not multi else
                                   "host memory over gloo (one-GPU rehearsal)" if staged else
-                                  "rt_comm_gather: grouped ncclSend / ncclRecv on the library's RCCL communicator, "
-                                  "root rotating over the ranks from one group of frames to the next"),
+                                  f"rt_comm_gather_frames: groups of {GROUP} frames, one grouped ncclSend / ncclRecv exchange per group "
+                                  "on the library's RCCL communicator, frame k gathered to rank k mod N"),
                        "render_flags": args.render_flags,
                        "scene_upload_ms": upload_s * 1e3,
                        "kernel_split_from": "last warm-up frame (fully instrumented, every kernel alone on the GPU)"},

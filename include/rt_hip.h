@@ -350,6 +350,23 @@ void rt_comm_destroy(RtComm *comm);
 int rt_comm_gather(RtComm *comm, const float *part_dev, size_t floats, float *gathered_dev, uint32_t root,
                    void *hip_stream);
 
+/* A GROUP of frames in one exchange, the root rotating from frame to frame: frame f of the group
+ * (f = 0 .. count-1) is gathered to rank (first_root + f) % world, so every GPU receives, un-tiles and
+ * sends home its share of the frames over its own PCIe link, and every xGMI link carries tiles in both
+ * directions at once instead of seven links converging on one GPU.  One call posts ONE send per
+ * (rank, root) pair and its receive, all inside one group.
+ * Layout, the same on every rank, in blocks of `floats` floats: with p = f % world and s = f / world,
+ * this rank's part of frame f lies at block p * slots + s of `parts_dev` (the frames of one root are
+ * adjacent, so they travel as one message), and the frame's root receives rank r's part of it at block
+ * r * slots + s of `gathered_dev`: rt_untile_device_pitched with gathered_dev + s * floats and a part
+ * pitch of slots * floats restores frame f there.  `slots` >= ceil(count / world) is the caller's choice
+ * (a fixed number lets a last, shorter group use the same buffers); both buffers hold world * slots
+ * blocks; gathered_dev may be NULL on a rank that is no frame's root.  Collective: every rank calls it
+ * with the same floats, count, first_root and slots.  rt_comm_gather is the case count = 1, slots = 1,
+ * first_root = root.  No counterpart in the reference. */
+int rt_comm_gather_frames(RtComm *comm, const float *parts_dev, size_t floats, uint32_t count, uint32_t first_root,
+                          uint32_t slots, float *gathered_dev, void *hip_stream);
+
 /* BVH::closest_hit on caller-supplied rays -- geometry/bvh.rs:140-142 with a
  * Hit record initialised as {t = tmax[r], t_min = tmin[r]} (shader/hit_struct.rs:17-39).
  * origins/directions: n x 3 doubles (host).  Outputs (host): t (f32, unchanged

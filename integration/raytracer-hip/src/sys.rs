@@ -305,6 +305,8 @@ extern "C" {
     pub fn rt_comm_destroy(comm: *mut RtComm);
     pub fn rt_comm_gather(comm: *mut RtComm, part_dev: *const f32, floats: usize, gathered_dev: *mut f32, root: u32,
                           hip_stream: *mut c_void) -> c_int;
+    pub fn rt_comm_gather_frames(comm: *mut RtComm, parts_dev: *const f32, floats: usize, count: u32, first_root: u32,
+                                 slots: u32, gathered_dev: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rt_trace_rays(backend: *mut RtBackend, dev_scene: *const RtDeviceScene, n: u64, origins: *const f64,
                          directions: *const f64, tmin: *const f64, tmax: *const f64, mode: i32, t_out: *mut f32,
                          shape_out: *mut i32, tri_out: *mut i32) -> c_int;

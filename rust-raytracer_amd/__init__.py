@@ -285,6 +285,7 @@ def lib() -> C.CDLL:
     L.rt_comm_destroy.argtypes = [vp]
     L.rt_comm_destroy.restype = None
     L.rt_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp]
+    L.rt_comm_gather_frames.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.rt_collect_timings.argtypes = [vp, C.POINTER(RtStats)]
     L.rt_trace_rays.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
     L.rt_partition_info.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RtRenderArgs), C.POINTER(C.c_uint32),
@@ -383,6 +384,22 @@ class Comm:
 
     def gather(self, part_dev_ptr: int, floats: int, gathered_dev_ptr: int, root: int = 0, stream: int = 0) -> None:
         _check(lib().rt_comm_gather(self._h, part_dev_ptr, floats, gathered_dev_ptr or None, root, stream or None))
+
+    def gather_frames(self, parts_dev_ptr: int, floats: int, count: int, first_root: int, slots: int,
+                      gathered_dev_ptr: int, stream: int = 0) -> None:
+        """rt_comm_gather_frames: `count` frames, frame f to rank (first_root + f) % world; see frame_blocks."""
+        _check(lib().rt_comm_gather_frames(self._h, parts_dev_ptr, floats, count, first_root, slots, gathered_dev_ptr or None,
+                                           stream or None))
+
+    @staticmethod
+    def frame_blocks(world: int, slots: int, f: int, first_root: int = 0):
+        """Where frame f of a group lives (rt_comm_gather_frames' layout): (root rank, block index of this
+        rank's part in the send buffer, block index of rank 0's part in the root's gather buffer); rank r's
+        part lies r * slots blocks further on."""
+        p, s = f % world, f // world
+        if s >= slots:
+            raise ValueError("frame does not fit: slots * world < frames of the group")
+        return (first_root + p) % world, p * slots + s, s
 
     def close(self) -> None:
         if self._h:

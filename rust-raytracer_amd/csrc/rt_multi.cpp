@@ -3,7 +3,8 @@
 // (RtComm).  Both post the same operations: every part that does not already lie in the root's
 // gather buffer is ONE ncclSend on its device and ONE ncclRecv on the root's, all inside one
 // group, so the seven senders of an eight-GPU node use their seven xGMI links to the root at the
-// same time.  Nothing else of a frame crosses a link.
+// same time; with a group of frames whose root rotates (rt_comm_gather_frames) every link carries
+// tiles in both directions at once.  Nothing else of a frame crosses a link.
 //
 // librccl is loaded with dlopen when the first communicator is made: a process that renders on one
 // GPU never maps it (the library is several hundred megabytes of kernels for every collective).
@@ -140,25 +141,42 @@ extern "C" void rt_comm_destroy(RtComm *c) {
     delete c;
 }
 
-extern "C" int rt_comm_gather(RtComm *c, const float *part_dev, size_t floats, float *gathered_dev, uint32_t root,
-                              void *hip_stream) {
-    if (!c || !part_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
-    if (root >= c->world) return rt::set_error(RT_ERR_INVALID, "root out of range");
-    if (c->rank == root && !gathered_dev) return rt::set_error(RT_ERR_INVALID, "the root needs a gather buffer");
-    if (floats == 0) return RT_OK;
+extern "C" int rt_comm_gather_frames(RtComm *c, const float *parts_dev, size_t floats, uint32_t count, uint32_t first_root,
+                                     uint32_t slots, float *gathered_dev, void *hip_stream) {
+    if (!c || !parts_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
+    const uint32_t world = c->world;
+    if (first_root >= world) return rt::set_error(RT_ERR_INVALID, "root out of range");
+    if ((uint64_t)slots * world < count) return rt::set_error(RT_ERR_INVALID, "slots * world must hold the group's frames");
+    if (floats == 0 || count == 0) return RT_OK;
+    // position p in the rotation: the root (first_root + p) % world receives the frames p, p + world, ...
+    auto frames_at = [&](uint32_t p) { return p < count ? (count - p + world - 1) / world : 0u; };
+    const uint32_t my_p = (c->rank + world - first_root) % world;
+    const uint32_t mine = frames_at(my_p);
+    if (mine && !gathered_dev) return rt::set_error(RT_ERR_INVALID, "a root needs a gather buffer");
     const Rccl *api = rccl();
     if (!api) return RT_ERR_DEVICE;
     RT_HIP(hipSetDevice(c->backend->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->backend->stream;
     RT_NCCL(api, api->GroupStart());
-    ncclResult_t r = api->Send(part_dev, floats, ncclFloat, (int)root, c->comm, stream);
-    if (c->rank == root)
-        for (uint32_t peer = 0; peer < c->world && r == ncclSuccess; ++peer)
-            r = api->Recv(gathered_dev + (size_t)peer * floats, floats, ncclFloat, (int)peer, c->comm, stream);
+    ncclResult_t r = ncclSuccess;
+    for (uint32_t p = 0; p < world && r == ncclSuccess; ++p) {
+        const uint32_t k = frames_at(p);
+        if (k) r = api->Send(parts_dev + (size_t)p * slots * floats, (size_t)k * floats, ncclFloat, (int)((first_root + p) % world), c->comm, stream);
+    }
+    if (mine)
+        for (uint32_t peer = 0; peer < world && r == ncclSuccess; ++peer)
+            r = api->Recv(gathered_dev + (size_t)peer * slots * floats, (size_t)mine * floats, ncclFloat, (int)peer, c->comm, stream);
     const ncclResult_t end = api->GroupEnd();
     RT_NCCL(api, r);
     RT_NCCL(api, end);
     return RT_OK;
+}
+
+extern "C" int rt_comm_gather(RtComm *c, const float *part_dev, size_t floats, float *gathered_dev, uint32_t root,
+                              void *hip_stream) {
+    if (c && root >= c->world) return rt::set_error(RT_ERR_INVALID, "root out of range");
+    if (c && c->rank == root && !gathered_dev) return rt::set_error(RT_ERR_INVALID, "the root needs a gather buffer");
+    return rt_comm_gather_frames(c, part_dev, floats, 1, root, 1, gathered_dev, hip_stream);
 }
 
 // ------------------------------------------------------------------ one process, several GPUs

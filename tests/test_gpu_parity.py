@@ -704,3 +704,73 @@ def test_bench_multi_gpu_path_with_one_rank(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 1e9
     assert "rt_comm_gather" in line["config"]["gather"]
+
+
+def test_bench_launches_its_own_ranks_and_rotates_the_root(tmp_path):
+    """`python bench.py --gpus 3` started plainly: it launches its three ranks itself.  They share this
+    machine's one GPU, so the parts travel through host memory (RT_BENCH_BACKEND=gloo) instead of RCCL,
+    but groups, block layout, rotating roots, un-tiling and the copy home are the code of a real run;
+    every rank compares the newest frame it delivered with the frame rendered whole, bit for bit."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_MULTI_PATH"):
+        env.pop(k, None)
+    # 20 steps: two whole groups of 8 frames and a last one of 4, whose first root is not rank 0
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "20", "--warmup", "2",
+                          "--no-cpu-baseline", "--workload", "spheres_and_triangles"], env=env, capture_output=True, text=True,
+                         timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 3 and line["config"]["rccl_ranks"] == 3 and line["steps"] == 20
+    assert "bit-identical" in line["config"]["frame_check"] and "each of the 3 ranks" in line["config"]["frame_check"]
+
+
+def test_comm_gather_frames_with_one_rank(rt, backend, scene_path):
+    """rt_comm_gather_frames: a group of frames in one exchange.  With a single rank every frame's root is
+    rank 0 and the exchange is a send to itself through RCCL: block f of the send buffer must arrive as
+    block f of the gather buffer, for a full group and for a shorter one, and blocks beyond the group stay
+    untouched.  The three 'frames' are the three parts of one frame, so un-tiling the received blocks must
+    give the frame rendered whole."""
+    import torch
+
+    W, H, tile, parts, slots = 250, 170, 16, 3, 5
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    whole, _, _ = dev.render(2)
+    comm = rt.Comm(backend, rt.Comm.make_id(), 0, 1)
+    a3 = dev.render_args(2, tile=(tile, tile), part=(0, parts))
+    _, _, stride = dev.partition_info(a3)
+    block = stride * tile * tile * 3
+    st = torch.cuda.Stream()
+    send = torch.zeros(slots * block, dtype=torch.float32, device="cuda")
+    recv = torch.full((slots * block,), -7.0, dtype=torch.float32, device="cuda")
+    fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for f in range(parts):
+        root, at, slot = rt.Comm.frame_blocks(1, slots, f)
+        assert (root, at, slot) == (0, f, f)
+        dev.render_device(dev.render_args(2, tile=(tile, tile), part=(f, parts)), send.data_ptr() + at * block * 4, stream=st.cuda_stream)
+    comm.gather_frames(send.data_ptr(), block, parts, 0, slots, recv.data_ptr(), stream=st.cuda_stream)
+    dev.untile_device(a3, recv.data_ptr(), fb.data_ptr(), stream=st.cuda_stream)
+    backend.sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(fb.cpu().numpy().reshape(H, W, 3), whole.pixels)
+    assert torch.equal(recv[: parts * block], send[: parts * block])
+    assert bool((recv[parts * block:] == -7.0).all())
+    # a shorter group through the same buffers
+    recv.fill_(-7.0)
+    torch.cuda.synchronize()
+    comm.gather_frames(send.data_ptr(), block, 1, 0, slots, recv.data_ptr(), stream=st.cuda_stream)
+    backend.sync()
+    torch.cuda.synchronize()
+    assert torch.equal(recv[:block], send[:block]) and bool((recv[block:] == -7.0).all())
+    with pytest.raises(rt.RtError):
+        comm.gather_frames(send.data_ptr(), block, slots + 1, 0, slots, recv.data_ptr(), stream=st.cuda_stream)
+    with pytest.raises(rt.RtError):
+        comm.gather_frames(send.data_ptr(), block, 1, 1, slots, recv.data_ptr(), stream=st.cuda_stream)
+    comm.close()
+    dev.close()

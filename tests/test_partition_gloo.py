@@ -5,6 +5,7 @@ rank 0, and rank 0 rebuilds the frame the way rt_untile_device does.  The result
 bit-identical with the unpartitioned frame (static tile map, ordered per-pixel sums).  Variants:
 three ranks with a smaller share for rank 0 (RtRenderArgs.part0_weight), and several frames
 gathered with one collective, which rank 0 receives as [rank][frame][block]."""
+import importlib
 import os
 import socket
 import sys
@@ -115,3 +116,27 @@ def test_gather_rebuilds_the_frame(tmp_path, world, weight, frames):
     if weight:
         # rank 0 took the smaller share (35 tiles over 21 lanes: the shares are coarse on this small grid)
         assert r["sizes"][0] <= r["sizes"][1:].min() and r["sizes"][0] < r["sizes"][1:].mean()
+
+
+def test_frame_exchange_layout_is_a_permutation():
+    """The block layout of rt_comm_gather_frames (Comm.frame_blocks): for every world size, group length
+    and first root, the frames of one root occupy adjacent blocks of the send buffer in frame order
+    (one message per root), no two frames share a block, and a root's frames land in distinct slots."""
+    rt = importlib.import_module("rust-raytracer_amd")
+    for world in (1, 2, 3, 4, 8):
+        for count in (1, 2, 4, 7, 8, 16):
+            slots = -(-count // world)
+            for first_root in range(world):
+                send_blocks, per_root = set(), {}
+                for f in range(count):
+                    root, at, slot = rt.Comm.frame_blocks(world, slots, f, first_root)
+                    assert root == (first_root + f) % world and 0 <= at < world * slots and at not in send_blocks
+                    send_blocks.add(at)
+                    per_root.setdefault(root, []).append((at, slot))
+                for root, frames in per_root.items():
+                    p = (root - first_root) % world
+                    assert [a for a, _ in frames] == list(range(p * slots, p * slots + len(frames)))
+                    assert [s for _, s in frames] == list(range(len(frames)))
+                    assert len(frames) == (count - p + world - 1) // world  # what the library sends to this root
+    with pytest.raises(ValueError):
+        rt.Comm.frame_blocks(2, 1, 2)
