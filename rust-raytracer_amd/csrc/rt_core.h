@@ -76,6 +76,7 @@ struct RtSceneView {
 // ---------------------------------------------------------------- small helpers
 
 RT_HD int32_t rt_as_int(float f) { return __builtin_bit_cast(int32_t, f); }
+RT_HD float rt_as_float(int32_t i) { return __builtin_bit_cast(float, i); }
 RT_HD float rt_fmax(float a, float b) { return __builtin_fmaxf(a, b); }  // NaN-ignoring, like f64::max
 RT_HD float rt_fmin(float a, float b) { return __builtin_fminf(a, b); }
 RT_HD double rt_dmax(double a, double b) { return __builtin_fmax(a, b); }
@@ -572,7 +573,7 @@ RT_HD rt_f2 rt_hi2(rt_f2 v) { return rt_f2{v.y, v.y}; }
 #endif
 
 struct FastTrav {
-    float ox, oy, oz, dx, dy, dz;  // current-space ray
+    rt_f2 px, py, pz;              // current-space ray, per axis (origin, direction): the operand shape of fast_triangle
     rt_f2 ixy;                     // clamped 1/d, x and y
     rt_f2 nxy;                     // -o * (1/d), x and y: a plane p is crossed at t = p * (1/d) + n
     rt_f2 zin;                     // (1/d.z, -o.z * (1/d.z))
@@ -596,7 +597,7 @@ RT_HD float rt_inv_clamped(float d) {
 }
 
 RT_HD void fast_set_ray(FastTrav &s, float ox, float oy, float oz, float dx, float dy, float dz) {
-    s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
+    s.px = rt_pair(ox, dx); s.py = rt_pair(oy, dy); s.pz = rt_pair(oz, dz);
     const float ix = rt_inv_clamped(dx), iy = rt_inv_clamped(dy);
     s.ixy = rt_pair(ix, iy);
     s.nxy = rt_pair(-(ox * ix), -(oy * iy));
@@ -628,8 +629,8 @@ template <class Stack>
 RT_HD void fast_begin(const RtSceneView &S, FastTrav &s, Stack &stk, const D3 &o, const D3 &d, float t0,
                       int32_t shape0, int32_t org_shape, int32_t org_tri) {
     fast_set_ray(s, (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
-    stk.set_aux(0, s.ox); stk.set_aux(1, s.oy); stk.set_aux(2, s.oz);
-    stk.set_aux(3, s.dx); stk.set_aux(4, s.dy); stk.set_aux(5, s.dz);
+    stk.set_aux(0, s.px.x); stk.set_aux(1, s.py.x); stk.set_aux(2, s.pz.x);
+    stk.set_aux(3, s.px.y); stk.set_aux(4, s.py.y); stk.set_aux(5, s.pz.y);
     s.t = t0;
     s.shape = shape0;
     s.tri = -1;
@@ -699,18 +700,14 @@ RT_HD void fast_box2_signed(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, c
 // uv0 = (u.x, v.x, u.y, v.y), uv1 = (u.z, v.z, u.w, v.w) (RtTriXf::uv), n = the height row.  gamma <= 1
 // needs no test of its own: beta >= 0 and beta <= 1 - gamma imply it (1 - gamma is exact near 1).
 RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &uv0, const rt_f4 &uv1, const rt_f4 &n, float tmin, float &t_out) {
-    const float hn = rt_fma(n.x, s.ox, rt_fma(n.y, s.oy, rt_fma(n.z, s.oz, n.w)));
-    const float dn = rt_fma(n.x, s.dx, rt_fma(n.y, s.dy, n.z * s.dz));
-    const float t = -hn * rt_rcp_approx(dn);
+    // each row of the map against origin and direction at once: (row . o, row . d); the row's
+    // coefficients are wave-uniform (scalar registers), so the broadcast costs nothing
+    const rt_f2 hn = rt_fma2(rt_pair(n.x, n.x), s.px, rt_fma2(rt_pair(n.y, n.y), s.py, rt_mul2(rt_pair(n.z, n.z), s.pz)));
+    const float t = -(hn.x + n.w) * rt_rcp_approx(hn.y);
     if (!(t >= tmin && t <= s.t)) return false;
-    // (beta, gamma) of the origin and their rates of change along the ray, both at once
-    const rt_f2 o2 = rt_fma2(rt_pair(uv0.x, uv0.y), rt_pair(s.ox, s.ox),
-                             rt_fma2(rt_pair(uv0.z, uv0.w), rt_pair(s.oy, s.oy),
-                                     rt_fma2(rt_pair(uv1.x, uv1.y), rt_pair(s.oz, s.oz), rt_pair(uv1.z, uv1.w))));
-    const rt_f2 d2 = rt_fma2(rt_pair(uv0.x, uv0.y), rt_pair(s.dx, s.dx),
-                             rt_fma2(rt_pair(uv0.z, uv0.w), rt_pair(s.dy, s.dy), rt_mul2(rt_pair(uv1.x, uv1.y), rt_pair(s.dz, s.dz))));
-    const rt_f2 bg = rt_fma2(rt_pair(t, t), d2, o2);
-    const float beta = bg.x, gamma = bg.y;
+    const rt_f2 bu = rt_fma2(rt_pair(uv0.x, uv0.x), s.px, rt_fma2(rt_pair(uv0.z, uv0.z), s.py, rt_mul2(rt_pair(uv1.x, uv1.x), s.pz)));
+    const rt_f2 gv = rt_fma2(rt_pair(uv0.y, uv0.y), s.px, rt_fma2(rt_pair(uv0.w, uv0.w), s.py, rt_mul2(rt_pair(uv1.y, uv1.y), s.pz)));
+    const float beta = rt_fma(t, bu.y, bu.x) + uv1.z, gamma = rt_fma(t, gv.y, gv.x) + uv1.w;
     if (!(gamma >= 0.0f)) return false;
     if (!(beta >= 0.0f && beta <= 1.0f - gamma)) return false;
     t_out = t;
@@ -724,10 +721,10 @@ RT_HD bool fast_triangle(const FastTrav &s, const rt_f4 &uv0, const rt_f4 &uv1, 
 RT_HD bool fast_payload_hit(const FastTrav &r, int32_t type, const rt_f4 &f0, const rt_f4 &f1, const rt_f4 &f2,
                             float tmin, float &t_out) {
     if (type == RT_SHAPE_SPHERE) {
-        const float ocx = r.ox - f0.x, ocy = r.oy - f0.y, ocz = r.oz - f0.z;
-        const float cd = ocx * r.dx + ocy * r.dy + ocz * r.dz;
-        const float dd = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
-        const float kx = ocy * r.dz - ocz * r.dy, ky = ocz * r.dx - ocx * r.dz, kz = ocx * r.dy - ocy * r.dx;
+        const float ocx = r.px.x - f0.x, ocy = r.py.x - f0.y, ocz = r.pz.x - f0.z;
+        const float cd = ocx * r.px.y + ocy * r.py.y + ocz * r.pz.y;
+        const float dd = r.px.y * r.px.y + r.py.y * r.py.y + r.pz.y * r.pz.y;
+        const float kx = ocy * r.pz.y - ocz * r.py.y, ky = ocz * r.px.y - ocx * r.pz.y, kz = ocx * r.py.y - ocy * r.px.y;
         const float disc = dd * (f0.w * f0.w) - (kx * kx + ky * ky + kz * kz);  // see sphere_f32
         if (!(disc >= 0.0f)) return false;
         const float sq = __builtin_sqrtf(disc), inv = 1.0f / dd;
@@ -740,15 +737,15 @@ RT_HD bool fast_payload_hit(const FastTrav &r, int32_t type, const rt_f4 &f0, co
     if (type == RT_SHAPE_TRIANGLE) {
         const float abx = f0.w, aby = f1.x, abz = f1.y, acx = f1.z, acy = f1.w, acz = f2.x;
         // c = ac x d ; det A = ab . c ; q = ab x ao ; see triangle_f32 for the determinants
-        const float cx = acy * r.dz - acz * r.dy, cy = acz * r.dx - acx * r.dz, cz = acx * r.dy - acy * r.dx;
+        const float cx = acy * r.pz.y - acz * r.py.y, cy = acz * r.px.y - acx * r.pz.y, cz = acx * r.py.y - acy * r.px.y;
         const float det_a = abx * cx + aby * cy + abz * cz;
         if (__builtin_fabsf(det_a) < 2.220446049250313e-16f) return false;
         const float inv_det = 1.0f / det_a;
-        const float aox = f0.x - r.ox, aoy = f0.y - r.oy, aoz = f0.z - r.oz;
+        const float aox = f0.x - r.px.x, aoy = f0.y - r.py.x, aoz = f0.z - r.pz.x;
         const float qx = aby * aoz - abz * aoy, qy = abz * aox - abx * aoz, qz = abx * aoy - aby * aox;
         const float t = -(acx * qx + acy * qy + acz * qz) * inv_det;
         if (!(t >= tmin && t <= r.t)) return false;
-        const float gamma = (r.dx * qx + r.dy * qy + r.dz * qz) * inv_det;
+        const float gamma = (r.px.y * qx + r.py.y * qy + r.pz.y * qz) * inv_det;
         if (!(gamma >= 0.0f && gamma <= 1.0f)) return false;
         const float beta = (aox * cx + aoy * cy + aoz * cz) * inv_det;
         if (!(beta >= 0.0f && beta <= 1.0f - gamma)) return false;
@@ -851,7 +848,7 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
                     if (is_inst) {
                         const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
                         const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
-                        const float wox = s.ox, woy = s.oy, woz = s.oz, wdx = s.dx, wdy = s.dy, wdz = s.dz;
+                        const float wox = s.px.x, woy = s.py.x, woz = s.pz.x, wdx = s.px.y, wdy = s.py.y, wdz = s.pz.y;
                         fast_set_ray(s, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
                                      ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
                                      ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
@@ -864,7 +861,7 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
                 } else if (shape_id != s.org_shape) {
                     // sphere / box / triangle at scene level, possibly instanced
                     FastTrav lr;
-                    fast_local_ray(S, first + k, is_inst, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz, s, lr);
+                    fast_local_ray(S, first + k, is_inst, s.px.x, s.py.x, s.pz.x, s.px.y, s.py.y, s.pz.y, s, lr);
                     float t;
                     if (fast_payload_hit(lr, is_inst ? proto_type : type, pp[1], pp[2], pp[3], tmin, t)) {
                         s.t = t;

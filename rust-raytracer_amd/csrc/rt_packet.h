@@ -119,7 +119,10 @@ __device__ inline void rt_fetch_48(const void *base, uint32_t off, rt_f4 &r0, rt
 // direction signs (bit k = negative on axis k), which turns the twelve min / max that sort each
 // slab's two plane distances into register choices made at compile time; OCT 8: mixed signs, the
 // general test.
-template <int OCT, int R>
+#ifndef RT_ANYHIT_ORDERED
+#define RT_ANYHIT_ORDERED 0
+#endif
+template <int OCT, int R, bool ORDERED>
 __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastTrav (&s)[R], float tmin, WaveStack &stk, int32_t cur,
                                                uint32_t dir_bits) {
     const char *node_base = reinterpret_cast<const char *>(S.nodes);
@@ -142,7 +145,7 @@ __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastT
         const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
         const int32_t ref_l = rt_as_int(l.x), ref_r = rt_as_int(l.y);
         const uint32_t order = (uint32_t)rt_as_int(l.z);  // RtNode::right_first_mask
-        const bool right_first = ((order >> (OCT < 8 ? (uint32_t)OCT : (dir_bits & 7u))) & 1u) != 0u;
+        const bool right_first = ORDERED && ((order >> (OCT < 8 ? (uint32_t)OCT : (dir_bits & 7u))) & 1u) != 0u;
         // two mirrored copies instead of selecting near / far operands: the branch is one scalar
         // instruction, the selects were six
         if (right_first) {
@@ -168,6 +171,171 @@ __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastT
     return cur;
 }
 
+// The same loop for one ray per lane and a known octant, written out in gfx950 assembly.  What the
+// compiler makes of the C++ above is fine in its vector half (6 packed multiply-adds, 8 min / max, 2
+// compares) but spends about 26 scalar instructions and 3 to 4 taken branches per node on the decision
+// that follows (uniform conditions widened to lane masks and narrowed again, copies between the arms
+// of its structured control flow), as much issue time per wave as the box test itself.  Here a node
+// costs 16 vector instructions, 9 to 16 scalar ones and 2 branches, and the broadcast operands of the
+// packed multiply-adds are picked with op_sel instead of being held twice (12 registers less).
+//
+// Registers: s[48:63] the node record (s[48:51] left x / y plane pairs, s[52:55] right, s[56:59] the z
+// pairs, s60 / s61 the child references, s62 RtNode::right_first_mask), s[64:67] the two ballots,
+// s[68:73] and v[48:61] scratch; all named in the clobber list.  The LDS stack is WaveStack's: row
+// `sp` receives the old top on a push, and the register copy of the top is refilled by a read that
+// is only waited for at the next record fetch -- or at the way out, the one place where the
+// compiler's code could otherwise see it unfinished.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WALK_ORDERED(OCT)                                        \
+    "s_bitcmp1_b32 s62, " OCT "\n\t"                                \
+    "s_cselect_b32 s48, s61, s60\n\t"                               \
+    "s_cselect_b32 s49, s60, s61\n\t"                               \
+    "s_cselect_b64 s[50:51], s[56:57], s[54:55]\n\t"                \
+    "s_cselect_b64 s[52:53], s[54:55], s[56:57]\n\t"
+#define RT_WALK_LEFT_FIRST                                          \
+    "s_mov_b32 s48, s60\n\t"                                        \
+    "s_mov_b32 s49, s61\n\t"                                        \
+    "s_mov_b64 s[50:51], s[54:55]\n\t"                              \
+    "s_mov_b64 s[52:53], s[56:57]\n\t"
+// E_* / X_*: the register of each plane pair that holds the entry / exit distance (left and right box)
+#define RT_WALK_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER)                      \
+    "1:\n\t"                                                                                                             \
+    "s_load_dwordx8 s[48:55], %[nb], %[cur]\n\t"                                                                         \
+    "s_load_dwordx8 s[56:63], %[nb], %[cur] offset:0x20\n\t"                                                             \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+    "s_nop 0\n\t"                                                                                                        \
+    "v_pk_fma_f32 v[48:49], s[48:49], %[ixy], %[nxy] op_sel_hi:[1,0,0]\n\t"                                              \
+    "v_pk_fma_f32 v[50:51], s[50:51], %[ixy], %[nxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                               \
+    "v_pk_fma_f32 v[52:53], s[56:57], %[zin], %[zin] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                               \
+    "v_pk_fma_f32 v[54:55], s[52:53], %[ixy], %[nxy] op_sel_hi:[1,0,0]\n\t"                                              \
+    "v_pk_fma_f32 v[56:57], s[54:55], %[ixy], %[nxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                               \
+    "v_pk_fma_f32 v[58:59], s[58:59], %[zin], %[zin] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                               \
+    "v_max_f32 v60, " E_LX ", " E_LY "\n\t"                                                                              \
+    "v_min_f32 v61, " X_LX ", " X_LY "\n\t"                                                                              \
+    "v_max3_f32 v60, v60, " E_LZ ", %[tmin]\n\t"                                                                         \
+    "v_min3_f32 v61, v61, " X_LZ ", %[t]\n\t"                                                                            \
+    "v_cmp_lt_f32_e64 s[54:55], v60, v61\n\t"                                                                            \
+    "v_max_f32 v60, " E_RX ", " E_RY "\n\t"                                                                              \
+    "v_min_f32 v61, " X_RX ", " X_RY "\n\t"                                                                              \
+    "v_max3_f32 v60, v60, " E_RZ ", %[tmin]\n\t"                                                                         \
+    "v_min3_f32 v61, v61, " X_RZ ", %[t]\n\t"                                                                            \
+    "v_cmp_lt_f32_e64 s[56:57], v60, v61\n\t"                                                                            \
+    ORDER /* s48 / s49 = first / second child, s[50:51] / s[52:53] = their ballots */                                    \
+    "s_cmp_lg_u64 s[50:51], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 3f\n\t"                                                                                              \
+    "s_mov_b32 %[cur], s48\n\t"                                                                                          \
+    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 5f\n\t"                                                                                              \
+    "s_lshl2_add_u32 s58, %[sp], %[base]\n\t" /* both: push the second */                                                \
+    "v_mov_b32 v60, s58\n\t"                                                                                             \
+    "ds_write_b32 v60, %[tos]\n\t"                                                                                       \
+    "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                      \
+    "s_max_i32 %[high], %[high], %[sp]\n\t"                                                                              \
+    "v_mov_b32 %[tos], s49\n\t"                                                                                          \
+    "s_branch 5f\n"                                                                                                      \
+    "3:\n\t"                                                                                                             \
+    "s_mov_b32 %[cur], s49\n\t"                                                                                          \
+    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 5f\n\t"                                                                                              \
+    "v_readfirstlane_b32 %[cur], %[tos]\n\t" /* neither: pop */                                                          \
+    "s_sub_i32 %[sp], %[sp], 1\n\t"                                                                                      \
+    "s_max_i32 %[sp], %[sp], 0\n\t"                                                                                      \
+    "s_lshl2_add_u32 s58, %[sp], %[base]\n\t"                                                                            \
+    "v_mov_b32 v60, s58\n\t"                                                                                             \
+    "ds_read_b32 %[tos], v60\n\t"                                                                                        \
+    "s_cmp_lt_i32 %[cur], 0\n\t"                                                                                         \
+    "s_cbranch_scc0 1b\n\t"                                                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+    "s_branch 6f\n"                                                                                                      \
+    "5:\n\t"                                                                                                             \
+    "s_cmp_lt_i32 %[cur], 0\n\t"                                                                                         \
+    "s_cbranch_scc0 1b\n"                                                                                                \
+    "6:\n\t"
+#define RT_WALK_ASM(...) RT_WALK_ASM_(__VA_ARGS__)
+// per axis: entry / exit register of the left box's pair, then of the right box's; a ray that runs towards
+// smaller coordinates enters a slab through its max plane, the second element of the pair
+#define RT_WALK_X_POS "v48", "v49", "v54", "v55"
+#define RT_WALK_X_NEG "v49", "v48", "v55", "v54"
+#define RT_WALK_Y_POS "v50", "v51", "v56", "v57"
+#define RT_WALK_Y_NEG "v51", "v50", "v57", "v56"
+#define RT_WALK_Z_POS "v52", "v53", "v58", "v59"
+#define RT_WALK_Z_NEG "v53", "v52", "v59", "v58"
+#define RT_WALK_RUN(TEXT)                                                                                                   \
+    asm volatile(TEXT                                                                                                       \
+                 : [cur] "+s"(cur), [sp] "+s"(sp), [high] "+s"(high), [tos] "+v"(tos)                                       \
+                 : [nb] "s"(node_base), [base] "s"(lds_base), [ixy] "v"(s.ixy), [nxy] "v"(s.nxy), [zin] "v"(s.zin),         \
+                   [tmin] "s"(tmin_u), [t] "v"(s.t)                                                                         \
+                 : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", \
+                   "s63", "v48", "v49", "v50", "v51", \
+                   "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "scc", "memory")
+
+template <int OCT, bool ORDERED>
+__device__ __forceinline__ int32_t packet_walk_asm(const RtSceneView &S, const FastTrav &s, float tmin, WaveStack &stk, int32_t cur) {
+    const void *node_base = S.nodes;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)stk.base;  // the low half of an LDS pointer is the LDS address
+    const float tmin_u = rt_as_float(__builtin_amdgcn_readfirstlane(rt_as_int(tmin)));
+    int32_t sp = __builtin_amdgcn_readfirstlane(stk.sp), high = __builtin_amdgcn_readfirstlane(stk.high), tos = stk.tos;
+    cur = __builtin_amdgcn_readfirstlane(cur);
+#define RT_WALK_CASE(N, X, Y, Z)                                                       \
+    if constexpr (OCT == N) {                                                          \
+        if constexpr (ORDERED) RT_WALK_RUN(RT_WALK_ASM(X, Y, Z, RT_WALK_ORDERED(#N))); \
+        else RT_WALK_RUN(RT_WALK_ASM(X, Y, Z, RT_WALK_LEFT_FIRST));                    \
+    }
+    RT_WALK_CASE(0, RT_WALK_X_POS, RT_WALK_Y_POS, RT_WALK_Z_POS)
+    RT_WALK_CASE(1, RT_WALK_X_NEG, RT_WALK_Y_POS, RT_WALK_Z_POS)
+    RT_WALK_CASE(2, RT_WALK_X_POS, RT_WALK_Y_NEG, RT_WALK_Z_POS)
+    RT_WALK_CASE(3, RT_WALK_X_NEG, RT_WALK_Y_NEG, RT_WALK_Z_POS)
+    RT_WALK_CASE(4, RT_WALK_X_POS, RT_WALK_Y_POS, RT_WALK_Z_NEG)
+    RT_WALK_CASE(5, RT_WALK_X_NEG, RT_WALK_Y_POS, RT_WALK_Z_NEG)
+    RT_WALK_CASE(6, RT_WALK_X_POS, RT_WALK_Y_NEG, RT_WALK_Z_NEG)
+    RT_WALK_CASE(7, RT_WALK_X_NEG, RT_WALK_Y_NEG, RT_WALK_Z_NEG)
+#undef RT_WALK_CASE
+    stk.sp = sp;
+    stk.high = high;
+    stk.tos = tos;
+    return cur;
+}
+#endif
+
+// One triangle of a leaf against the lane's ray: fetches the triangle's map (RtTriXf, 48 bytes at
+// tri_base + at) and returns t, beta and gamma as fast_triangle computes them, operation for operation;
+// the caller applies the acceptance rules.  Each row of the map meets the ray as three packed
+// multiply-adds over the (origin, direction) pairs, the row's coefficient broadcast from its scalar
+// register pair by op_sel: 16 vector instructions, none of them a copy.  (Left to the compiler, the same
+// arithmetic is re-paired by its vectoriser into shuffles and, at this register budget, a round trip
+// through scratch memory inside the loop.)  The reciprocal is issued early: its result may not feed
+// an ordinary vector instruction in the next two issue slots on this chip.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32_t at, const FastTrav &s, float &t, float &beta,
+                                                    float &gamma) {
+    // s[48:51] = (u.x, v.x, u.y, v.y), s[52:55] = (u.z, v.z, u.w, v.w), s[56:59] = the height row n
+    asm("s_load_dwordx8 s[48:55], %[tb], %[at]\n\t"
+        "s_load_dwordx4 s[56:59], %[tb], %[at] offset:0x20\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_nop 0\n\t"
+        "v_pk_mul_f32 v[48:49], %[pz], s[58:59] op_sel_hi:[1,0]\n\t"                             // n.z * (oz, dz)
+        "v_pk_fma_f32 v[48:49], %[py], s[56:57], v[48:49] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"  // + n.y * (oy, dy)
+        "v_pk_fma_f32 v[48:49], %[px], s[56:57], v[48:49] op_sel_hi:[1,0,1]\n\t"                 // + n.x * (ox, dx)
+        "v_pk_mul_f32 v[50:51], %[pz], s[52:53] op_sel_hi:[1,0]\n\t"                             // u.z
+        "v_rcp_f32 v49, v49\n\t"
+        "v_pk_mul_f32 v[52:53], %[pz], s[52:53] op_sel:[0,1] op_sel_hi:[1,1]\n\t"                // v.z
+        "v_pk_fma_f32 v[50:51], %[py], s[50:51], v[50:51] op_sel_hi:[1,0,1]\n\t"                 // u.y
+        "v_pk_fma_f32 v[52:53], %[py], s[50:51], v[52:53] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"  // v.y
+        "v_pk_fma_f32 v[50:51], %[px], s[48:49], v[50:51] op_sel_hi:[1,0,1]\n\t"                 // u.x
+        "v_pk_fma_f32 v[52:53], %[px], s[48:49], v[52:53] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"  // v.x
+        "v_add_f32 v48, s59, v48\n\t"                                                            // n . o + n.w
+        "v_mul_f32_e64 %[t], -v48, v49\n\t"
+        "v_fma_f32 %[b], %[t], v51, v50\n\t"
+        "v_fma_f32 %[g], %[t], v53, v52\n\t"
+        "v_add_f32 %[b], s54, %[b]\n\t"
+        "v_add_f32 %[g], s55, %[g]\n\t"
+        : [t] "=&v"(t), [b] "=&v"(beta), [g] "=&v"(gamma)
+        : [tb] "s"(tri_base), [at] "s"(at), [px] "v"(s.px), [py] "v"(s.py), [pz] "v"(s.pz)
+        : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "v48", "v49", "v50", "v51", "v52",
+          "v53");
+}
+#endif
+
 // Traverses the scene with the wave's 64 * R rays (R per lane).  On entry s[r] holds the lane's
 // r-th world-space ray, search bound s[r].t (-inf for a slot without a ray), s[r].shape / .tri =
 // initial hit, and the origin primitive.  `lds_rows`: max_sp + 1 dwords for the stack, followed
@@ -185,8 +353,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         live[r] = s[r].t > ninf;
-        world[(r * 6 + 0) * 64] = s[r].ox; world[(r * 6 + 1) * 64] = s[r].oy; world[(r * 6 + 2) * 64] = s[r].oz;
-        world[(r * 6 + 3) * 64] = s[r].dx; world[(r * 6 + 4) * 64] = s[r].dy; world[(r * 6 + 5) * 64] = s[r].dz;
+        world[(r * 6 + 0) * 64] = s[r].px.x; world[(r * 6 + 1) * 64] = s[r].py.x; world[(r * 6 + 2) * 64] = s[r].pz.x;
+        world[(r * 6 + 3) * 64] = s[r].px.y; world[(r * 6 + 4) * 64] = s[r].py.y; world[(r * 6 + 5) * 64] = s[r].pz.y;
     }
     const uint32_t world_bits = packet_direction_bits<R>(s, live);
     uint32_t dir_bits = world_bits;
@@ -197,16 +365,23 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
     bool in_instance = false;
     for (;;) {
         if (cur >= 0) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
+#define RT_PACKET_WALK(N) \
+    (R == 1 ? packet_walk_asm<N, !ANYHIT || RT_ANYHIT_ORDERED>(S, s[0], tmin, stk, cur) \
+            : packet_walk<N, R, !ANYHIT || RT_ANYHIT_ORDERED>(S, s, tmin, stk, cur, dir_bits))
+#else
+#define RT_PACKET_WALK(N) packet_walk<N, R, !ANYHIT || RT_ANYHIT_ORDERED>(S, s, tmin, stk, cur, dir_bits)
+#endif
             switch (dir_bits) {
-            case 0: cur = packet_walk<0, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 1: cur = packet_walk<1, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 2: cur = packet_walk<2, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 3: cur = packet_walk<3, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 4: cur = packet_walk<4, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 5: cur = packet_walk<5, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 6: cur = packet_walk<6, R>(S, s, tmin, stk, cur, dir_bits); break;
-            case 7: cur = packet_walk<7, R>(S, s, tmin, stk, cur, dir_bits); break;
-            default: cur = packet_walk<8, R>(S, s, tmin, stk, cur, dir_bits); break;
+            case 0: cur = RT_PACKET_WALK(0); break;
+            case 1: cur = RT_PACKET_WALK(1); break;
+            case 2: cur = RT_PACKET_WALK(2); break;
+            case 3: cur = RT_PACKET_WALK(3); break;
+            case 4: cur = RT_PACKET_WALK(4); break;
+            case 5: cur = RT_PACKET_WALK(5); break;
+            case 6: cur = RT_PACKET_WALK(6); break;
+            case 7: cur = RT_PACKET_WALK(7); break;
+            default: cur = packet_walk<8, R, !ANYHIT || RT_ANYHIT_ORDERED>(S, s, tmin, stk, cur, dir_bits); break;
             }
         }
         if (cur == RT_REF_NONE) break;
@@ -234,6 +409,19 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
             uint32_t at = first * (uint32_t)sizeof(RtTriXf);
             for (uint32_t k = 0; k < cnt; ++k, at += (uint32_t)sizeof(RtTriXf)) {
                 const int32_t gtri = (int32_t)(first + k);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
+                if constexpr (R == 1) {
+                    float t, beta, gamma;
+                    packet_triangle_asm(tri_base, at, s[0], t, beta, gamma);
+                    const bool hit = t >= tmin && t <= s[0].t && gamma >= 0.0f && beta >= 0.0f && beta <= 1.0f - gamma;
+                    if (hit && gtri != own_tri[0]) {
+                        s[0].shape = cur_shape;
+                        s[0].tri = gtri;
+                        s[0].t = ANYHIT ? ninf : t;
+                    }
+                    continue;
+                }
+#endif
                 rt_f4 uv0, uv1, tn;
                 rt_fetch_48(tri_base, at, uv0, uv1, tn);
 #pragma unroll
@@ -278,7 +466,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                     rt_fetch_48(S.tprim_xf, (first + k) * 48u, r0, r1, r2);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const float wox = s[r].ox, woy = s[r].oy, woz = s[r].oz, wdx = s[r].dx, wdy = s[r].dy, wdz = s[r].dz;
+                        const float wox = s[r].px.x, woy = s[r].py.x, woz = s[r].pz.x, wdx = s[r].px.y, wdy = s[r].py.y, wdz = s[r].pz.y;
                         fast_set_ray(s[r], ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
                                      ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
                                      ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
@@ -300,7 +488,7 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                     bool hit;
                     if (is_inst) {
                         FastTrav lr;
-                        fast_local_ray(S, first + k, true, s[r].ox, s[r].oy, s[r].oz, s[r].dx, s[r].dy, s[r].dz, s[r], lr);
+                        fast_local_ray(S, first + k, true, s[r].px.x, s[r].py.x, s[r].pz.x, s[r].px.y, s[r].py.y, s[r].pz.y, s[r], lr);
                         hit = fast_payload_hit(lr, proto_type, f0, f1, f2, tmin, t);
                     } else {
                         hit = fast_payload_hit(s[r], type, f0, f1, f2, tmin, t);
