@@ -67,12 +67,13 @@ def pmc_profile(workload, kernel_class):
     """The committed counter profile of this workload (profiles/pmc_traffic.json, written by
     tools/summarize_pmc.py from separate rocprofv3 --pmc passes over `bench.py --flights 1`): figures
     of the kernel with the most device time, and the HBM bytes of a whole frame.  None when the
-    profile is missing or was taken for another dominant kernel."""
+    profile is missing or was taken for another dominant kernel (kernel_class None: any kernel will do,
+    for the whole-frame figures)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             entry = json.load(f).get(workload)
-        if entry and entry.get("kernel", "").startswith(KERNEL_OF_CLASS.get(kernel_class, ())):
+        if entry and (kernel_class is None or entry.get("kernel", "").startswith(KERNEL_OF_CLASS.get(kernel_class, ()))):
             return entry
     except Exception:
         pass
@@ -452,7 +453,19 @@ def main():
         hbm_true = None
         if solo_ms is None:  # N > 1: the instrumented warm-up frame's figure (its kernels also ran alone)
             solo_ms = k_ms[dom] / max(k_n[dom], 1)
+        roof_note = None
+        if dom_name not in ("trace_closest", "trace_shadow"):
+            # The stage with the most device time is not a traversal (a mirror scene: the f64 shade stage, one
+            # launch per bounce, bound by the latency of its dependent loads; it has no byte yardstick).  The
+            # HBM object is then given for the traversal class with the most time, and says so.
+            roof_note = f"the class with the most device time is '{dom_name}'; figures are for the dominant traversal class"
+            dom = max((k for k in range(len(rt.KERNEL_CLASSES)) if rt.KERNEL_CLASSES[k] in ("trace_closest", "trace_shadow")),
+                      key=lambda k: k_ms[k])
+            dom_name = rt.KERNEL_CLASSES[dom]
+            solo_ms = k_ms[dom] / max(k_n[dom], 1)
+            solo_launches = 0
         prof = pmc_profile(args.workload, dom_name) if not multi else None
+        prof_frame = pmc_profile(args.workload, None) if not multi else None
         if ab is not None and dom_name in ("trace_closest", "trace_shadow"):
             if dom_name == "trace_shadow":
                 bytes_per_step = s0.shadow_rays * ab["shadow"]["bytes_per_ray"]
@@ -477,6 +490,8 @@ def main():
             if prof:
                 roofline["counters"] = {k: prof.get(k) for k in ("hbm_gbs", "l2_hit_rate", "valu_lane_utilisation")}
                 roofline["traffic_frac"] = prof["bytes"] / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if roof_note:
+                roofline["note"] = roof_note
         if prof and prof.get("valu_wave_insts"):
             # What does bound the kernel: instruction issue.  A wave64 vector instruction occupies its SIMD
             # for 4 cycles; the scalar unit of a compute unit issues one instruction per cycle.
@@ -486,9 +501,13 @@ def main():
             roofline_issue = {"kernel": prof["kernel"], "valu_wave_insts": prof["valu_wave_insts"], "scalar_insts": prof["scalar_insts"],
                               "clock_ghz": CLOCK_GHZ, "valu_bound_ms": valu_ms, "scalar_bound_ms": scalar_ms, "bound_ms": bound_ms,
                               "kernel_ms": solo_ms, "frac": bound_ms / solo_ms,
-                              "from": "instruction counts per launch: profiles/pmc_traffic.json (rocprofv3 --pmc); kernel_ms: live, as roofline.avg_launch_ms"}
-        if prof and prof.get("frame_hbm_bytes"):
-            hbm_true = prof["frame_hbm_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+                              "from": "instruction counts per launch: profiles/pmc_traffic.json (rocprofv3 --pmc); kernel_ms: live, as roofline.avg_launch_ms",
+                              # the duration of the same kernel in the kernel trace taken with the counter passes: when it
+                              # is far from the live one, the committed counts belong to another version of the kernel
+                              "kernel_ms_in_profile": prof["avg_us"] * 1e-3 if prof.get("avg_us") else None,
+                              "profile_matches_this_build": (abs(prof["avg_us"] * 1e-3 - solo_ms) <= 0.1 * solo_ms) if prof.get("avg_us") else None}
+        if prof_frame and prof_frame.get("frame_hbm_bytes"):
+            hbm_true = prof_frame["frame_hbm_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         if roofline is not None and not multi:
             torch.cuda.set_stream(torch.cuda.default_stream())
             hbm = measured_hbm_gbs(torch)

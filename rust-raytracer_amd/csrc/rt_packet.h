@@ -119,6 +119,10 @@ __device__ inline void rt_fetch_48(const void *base, uint32_t off, rt_f4 &r0, rt
 // direction signs (bit k = negative on axis k), which turns the twelve min / max that sort each
 // slab's two plane distances into register choices made at compile time; OCT 8: mixed signs, the
 // general test.
+// Any-hit packets (shadow rays) visit the left child first instead of the nearer one: which blocker a
+// ray finds first does not matter to "blocked or not", most shadow rays of a frame are not blocked at
+// all and visit the same nodes in any order, and the walk saves the order test (bunny frame: shadow
+// kernel -5 %).  Closest-hit packets keep the nearer child first: an early hit shortens every later test.
 #ifndef RT_ANYHIT_ORDERED
 #define RT_ANYHIT_ORDERED 0
 #endif

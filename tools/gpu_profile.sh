@@ -12,8 +12,6 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="bench.py --no-cpu-baseline --steps 20 --warmup 3 --workload $WL --mode $MODE"
 SOLO="$BENCH --flights 1"
-timeout -k 10 300 python3 $BENCH > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
-cat $OUT/bench.json
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH > $OUT/trace.txt 2>&1 || { tail -5 $OUT/trace.txt; exit 1; }
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_solo -- python3 $SOLO > $OUT/trace_solo.txt 2>&1 || { tail -5 $OUT/trace_solo.txt; exit 1; }
 pass() {
@@ -31,6 +29,21 @@ pass tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum &&
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 python3 tools/summarize_pmc.py $OUT --json $OUT/summary.json --traffic-json $OUT/pmc_traffic.json --workload $WL > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
+# the bench line last, with this run's counts in place: its issue-rate and traffic figures are computed
+# from profiles/pmc_traffic.json and must belong to the kernels that were just measured
+python3 - "$OUT/pmc_traffic.json" <<'PY'
+import json, sys
+new = json.load(open(sys.argv[1]))
+try:
+    cur = json.load(open("profiles/pmc_traffic.json"))
+except Exception:
+    cur = {}
+cur.update(new)
+json.dump(cur, open("profiles/pmc_traffic.json", "w"), indent=1)
+PY
+cp profiles/pmc_traffic.json $OUT/pmc_traffic_merged.json
+timeout -k 10 300 python3 $BENCH > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+cat $OUT/bench.json
 # keep only the small files: the raw per-dispatch CSVs are large
 find $OUT -name "*_counter_collection.csv" -size +8M -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
