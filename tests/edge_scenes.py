@@ -103,3 +103,15 @@ def ggx_scene(roughness=0.25, samples=3, mirror_type=None):
     return json.dumps({"scene": {"camera": CAM, "shader": shaders, "shape": shapes,
                                  "light": [POINT, {"_type": "point", "position": "-4 2.5 3", "intensity": "0.5 0.5 0.6"}, AMBIENT],
                                  "sceneParameters": {"bgColor": "0.2 0.25 0.35"}}})
+
+
+def two_sphere_scene_of_the_reference_test():
+    """The scene of the reference's own (commented-out) BVH test, geometry/bvh.rs:149-183: unit spheres
+    at (0, 0, -5) and (2, 0, -5)."""
+    import json
+
+    shapes = [{"_name": "sphere1", "_type": "sphere", "shader": "m", "center": "0 0 -5", "radius": 1.0},
+              {"_name": "sphere2", "_type": "sphere", "shader": "m", "center": "2 0 -5", "radius": 1.0}]
+    return json.dumps({"scene": {
+        "camera": [{"_name": "main", "_type": "perspective", "position": "0 0 0", "viewDir": "0 0 -1", "focalLength": 1.0}],
+        "shader": [{"_name": "m", "_type": "Lambertian", "diffuse": "1 1 1"}], "shape": shapes}})

@@ -164,3 +164,25 @@ def test_fast_scene_tree_holds_the_reachable_shapes(rt, scene_path, tmp_path):
                 assert (b_fast[c][:3] >= b_fast[i][:3]).all() and (b_fast[c][3:] <= b_fast[i][3:]).all()
             return end
         assert check(0) == len(k_fast)
+
+
+def test_reference_bvh_construction_case(rt):
+    """geometry/bvh.rs:156-182 asserts that the root box of that two-sphere tree is hit by the ray from the
+    origin along -z over [0, inf).  Here: both builders give one leaf of two spheres whose box is
+    [-1, 3] x [-1, 1] x [-6, -4] (BBox::combine of the spheres' boxes, sphere.rs:91-96), the oracle's
+    BBox::hit accepts that ray, and the walk (oracle and host build of the device code) finds sphere1 at
+    t = 4."""
+    import edge_scenes
+
+    sc = rt.parse_scene(edge_scenes.two_sphere_scene_of_the_reference_test(), "")
+    ko, po, bo = O.bvh_dump(sc, -1)
+    kp, pp, bp, _ = HS.bvh_dump(sc, -1)
+    assert np.array_equal(ko, kp) and np.array_equal(po, pp) and np.array_equal(bo, bp)
+    assert ko.tolist() == [2] and po.tolist() == [0, 1]
+    assert bo.reshape(-1, 6)[0].tolist() == [-1.0, -1.0, -6.0, 3.0, 1.0, -4.0]
+    assert O.bbox_hit((-1, -1, -6), (3, 1, -4), (0, 0, 0), (0, 0, -1), 0.0, float("inf")) == 4.0  # is_some(), entry t
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        t, shape, tri = HS.trace_rays(sc, [(0, 0, 0)], [(0, 0, -1)], 0.0, float("inf"), mode=mode)
+        assert (float(t[0]), int(shape[0])) == (4.0, 0)
+    t, shape, tri, normal = O.trace_rays(sc, [(0, 0, 0)], [(0, 0, -1)], 0.0, float("inf"))
+    assert (float(t[0]), int(shape[0]), normal[0].tolist()) == (4.0, 0, [0.0, 0.0, 1.0])

@@ -138,3 +138,23 @@ def test_cuboid_cases_on_the_device(rt, backend, mode):
     assert trace_one(rt, backend, text, [0.2, -9, 0.3], [0, 1, 0], 1.0, INF, mode) == (7.0, 0)
     t, shape = trace_one(rt, backend, text, [0, 0, 0], [0, 0, -1], 0.5, INF, mode)  # from inside: t_min
     assert shape == 0 and t == 0.5
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reference_bvh_construction_case_on_the_device(rt, backend, mode):
+    """geometry/bvh.rs:149-183 (a test the reference keeps commented out): two unit spheres at (0, 0, -5)
+    and (2, 0, -5), a ray from the origin along -z over [0, inf) must hit the tree's root box.  On the
+    device the walk must go on to find sphere1 at t = 4, through rt_trace_rays and as the only camera ray
+    of a 1 x 1 frame (t_min = 1, the same answer)."""
+    from edge_scenes import two_sphere_scene_of_the_reference_test
+
+    scene = rt.parse_scene(two_sphere_scene_of_the_reference_test(), "", image_width=1, image_height=1, recursion_depth=0)
+    dev = backend.upload(scene)
+    t, shape, tri = dev.trace_rays([(0, 0, 0)], [(0, 0, -1)], 0.0, INF, mode=mode)
+    assert (float(t[0]), int(shape[0]), int(tri[0])) == (4.0, 0, -1)
+    # from a point between the spheres' boxes and the second sphere: only sphere2
+    t, shape, tri = dev.trace_rays([(2, 0, 0)], [(0, 0, -1)], 0.0, INF, mode=mode)
+    assert (float(t[0]), int(shape[0])) == (4.0, 1)
+    fb, ids, stats = dev.render(1, mode=mode, want_ids=True)
+    assert int(ids.primary_shape[0]) == 0 and stats.primary_rays == 1
+    dev.close()
