@@ -176,6 +176,26 @@ RT_HD void queue_read_ray(const RtBuffers &Q, int which, uint32_t slot, D3 &o, D
     d = D3{RT_STREAM_LD(Q.q_d[which][0][slot]), RT_STREAM_LD(Q.q_d[which][1][slot]), RT_STREAM_LD(Q.q_d[which][2][slot])};
 }
 
+// Normal and ray direction of a lit hit in the lit table.  Where the light sums are the reference's f64
+// arithmetic the vectors are kept as computed; where the sums run in f32 (add_light<true> rounds them
+// first thing) they are stored rounded, in the front half of the same arrays: 12 bytes each instead of 24.
+RT_HD void lit_store_vec(double *const (&arr)[3], uint32_t sample, const D3 &v, bool as_f32) {
+    if (as_f32) {
+        RT_STREAM_ST(reinterpret_cast<float *>(arr[0])[sample], (float)v.x);
+        RT_STREAM_ST(reinterpret_cast<float *>(arr[1])[sample], (float)v.y);
+        RT_STREAM_ST(reinterpret_cast<float *>(arr[2])[sample], (float)v.z);
+    } else {
+        RT_STREAM_ST(arr[0][sample], v.x); RT_STREAM_ST(arr[1][sample], v.y); RT_STREAM_ST(arr[2][sample], v.z);
+    }
+}
+RT_HD D3 lit_load_vec(double *const (&arr)[3], uint32_t sample, bool as_f32) {
+    if (as_f32)
+        return D3{(double)RT_STREAM_LD(reinterpret_cast<const float *>(arr[0])[sample]),
+                  (double)RT_STREAM_LD(reinterpret_cast<const float *>(arr[1])[sample]),
+                  (double)RT_STREAM_LD(reinterpret_cast<const float *>(arr[2])[sample])};
+    return D3{RT_STREAM_LD(arr[0][sample]), RT_STREAM_LD(arr[1][sample]), RT_STREAM_LD(arr[2][sample])};
+}
+
 // ---- trace (closest): render.rs:70 / perfect_mirror.rs:27.
 // Hit::new gives camera rays t_min = 1.0 (hit_struct.rs:20); mirror rays get
 // VERY_SMALL_NUMBER (perfect_mirror.rs:25).  idx = local sample (bounce 0) or queue slot.
@@ -312,8 +332,8 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
     case RT_SHADER_LAMBERTIAN:
     case RT_SHADER_BLINN_PHONG: {
         RT_STREAM_ST(Q.l_p[0][sample], p.x); RT_STREAM_ST(Q.l_p[1][sample], p.y); RT_STREAM_ST(Q.l_p[2][sample], p.z);
-        RT_STREAM_ST(Q.l_n[0][sample], n.x); RT_STREAM_ST(Q.l_n[1][sample], n.y); RT_STREAM_ST(Q.l_n[2][sample], n.z);
-        RT_STREAM_ST(Q.l_d[0][sample], d.x); RT_STREAM_ST(Q.l_d[1][sample], d.y); RT_STREAM_ST(Q.l_d[2][sample], d.z);
+        lit_store_vec(Q.l_n, (uint32_t)sample, n, B.light_sums_f32 != 0u);
+        if (sh.type == RT_SHADER_BLINN_PHONG) lit_store_vec(Q.l_d, (uint32_t)sample, d, B.light_sums_f32 != 0u);  // only its highlight looks at the ray
         RT_STREAM_ST(Q.l_shape[sample], shape);
         RT_STREAM_ST(Q.l_tri[sample], gtri);
         uint32_t self_mask = 0;
@@ -461,9 +481,9 @@ RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint
 template <bool F32>
 RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, uint32_t blocked) {
     const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
-    const D3 n = D3{RT_STREAM_LD(Q.l_n[0][sample]), RT_STREAM_LD(Q.l_n[1][sample]), RT_STREAM_LD(Q.l_n[2][sample])};
-    const D3 d = D3{RT_STREAM_LD(Q.l_d[0][sample]), RT_STREAM_LD(Q.l_d[1][sample]), RT_STREAM_LD(Q.l_d[2][sample])};
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
+    const D3 n = lit_load_vec(Q.l_n, sample, F32);
+    const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, F32) : D3{0.0, 0.0, -1.0};
     ColorF color = {0.0f, 0.0f, 0.0f};
     int slot = 0;
     for (int li = 0; li < S.n_lights; ++li) {
@@ -483,9 +503,9 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
     const int32_t shape = Q.l_shape[sample];
     if (shape < 0) return false;
     const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
-    const D3 n = D3{RT_STREAM_LD(Q.l_n[0][sample]), RT_STREAM_LD(Q.l_n[1][sample]), RT_STREAM_LD(Q.l_n[2][sample])};
-    const D3 d = D3{RT_STREAM_LD(Q.l_d[0][sample]), RT_STREAM_LD(Q.l_d[1][sample]), RT_STREAM_LD(Q.l_d[2][sample])};
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
+    const D3 n = lit_load_vec(Q.l_n, sample, B.light_sums_f32 != 0u);
+    const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, B.light_sums_f32 != 0u) : D3{0.0, 0.0, -1.0};
     const bool want_ids = ids.shadow_shape || ids.shadow_tri;
     const size_t gs = want_ids ? global_sample(B, sample) : 0;
     ColorF color = {0.0f, 0.0f, 0.0f};
