@@ -293,7 +293,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
                     self = ((RT_STREAM_LD(Q.l_self[sample]) >> ls) & 1u) != 0u;
                     trace = !self;
                     if (trace) {
-                        o = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+                        o = lit_load_vec(Q.l_p, sample, true);  // the fused kernel is fast mode's
                         d = d3(S.lights[S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
                     }
                 }
@@ -793,7 +793,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     } else if ((rc = ensure_buffers(be, capacity, ds->n_point_lights))) {
         return rc;
     }
-    const RtBuffers Q = static_memory ? carved : be->buf;
+    RtBuffers Q = static_memory ? carved : be->buf;
+    Q.lit_f32 = args->mode == RT_MODE_REFERENCE_ORDER ? 0u : 1u;
     const RtSceneView &S = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view : ds->view_fast;
 
     RtIdOut io{};

@@ -74,6 +74,7 @@ struct RtBuffers {
                              // their exclusive prefix sums; lies behind the counters and is cleared with them
     uint32_t *lit_list;      // samples that have a lit hit, ascending
     uint32_t capacity;       // samples a batch can hold
+    uint32_t lit_f32;        // set per frame: the lit table's vectors are stored as f32 (fast mode), see lit_store_vec
 };
 
 #define RT_LIT_CHUNK 1024u
@@ -176,9 +177,10 @@ RT_HD void queue_read_ray(const RtBuffers &Q, int which, uint32_t slot, D3 &o, D
     d = D3{RT_STREAM_LD(Q.q_d[which][0][slot]), RT_STREAM_LD(Q.q_d[which][1][slot]), RT_STREAM_LD(Q.q_d[which][2][slot])};
 }
 
-// Normal and ray direction of a lit hit in the lit table.  Where the light sums are the reference's f64
-// arithmetic the vectors are kept as computed; where the sums run in f32 (add_light<true> rounds them
-// first thing) they are stored rounded, in the front half of the same arrays: 12 bytes each instead of 24.
+// Point, normal and ray direction of a lit hit in the lit table.  In reference-order mode the vectors are
+// kept as computed (f64).  In fast mode their consumers round them to f32 first thing -- the shadow rays'
+// tree search takes an f32 origin, add_light<true> f32 vectors -- so they are stored rounded, in the
+// front half of the same arrays: 12 bytes each instead of 24 (RtBuffers::lit_f32).
 RT_HD void lit_store_vec(double *const (&arr)[3], uint32_t sample, const D3 &v, bool as_f32) {
     if (as_f32) {
         RT_STREAM_ST(reinterpret_cast<float *>(arr[0])[sample], (float)v.x);
@@ -331,9 +333,9 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
     switch (sh.type) {
     case RT_SHADER_LAMBERTIAN:
     case RT_SHADER_BLINN_PHONG: {
-        RT_STREAM_ST(Q.l_p[0][sample], p.x); RT_STREAM_ST(Q.l_p[1][sample], p.y); RT_STREAM_ST(Q.l_p[2][sample], p.z);
-        lit_store_vec(Q.l_n, (uint32_t)sample, n, B.light_sums_f32 != 0u);
-        if (sh.type == RT_SHADER_BLINN_PHONG) lit_store_vec(Q.l_d, (uint32_t)sample, d, B.light_sums_f32 != 0u);  // only its highlight looks at the ray
+        lit_store_vec(Q.l_p, (uint32_t)sample, p, Q.lit_f32 != 0u);
+        lit_store_vec(Q.l_n, (uint32_t)sample, n, Q.lit_f32 != 0u);
+        if (sh.type == RT_SHADER_BLINN_PHONG) lit_store_vec(Q.l_d, (uint32_t)sample, d, Q.lit_f32 != 0u);  // only its highlight looks at the ray
         RT_STREAM_ST(Q.l_shape[sample], shape);
         RT_STREAM_ST(Q.l_tri[sample], gtri);
         uint32_t self_mask = 0;
@@ -407,7 +409,7 @@ RT_HD bool shadow_setup(const RtSceneView &S, const RtBuffers &Q, uint32_t light
     if (ANYHIT && r.shape0 >= 0) return false;
     r.org_tri = Q.l_tri[sample];
     const RtLight &light = S.lights[S.point_lights[light_slot]];
-    r.o = D3{Q.l_p[0][sample], Q.l_p[1][sample], Q.l_p[2][sample]};
+    r.o = lit_load_vec(Q.l_p, sample, Q.lit_f32 != 0u);
     r.d = d3(light.position) - r.o;  // Ray::atob, ray.rs:15-20
     return true;
 }
@@ -419,13 +421,13 @@ RT_HD bool shadow_setup_lit(const RtSceneView &S, const RtBuffers &Q, uint32_t l
     const size_t k = (size_t)light_slot * Q.capacity + sample;
     const int32_t org_shape = RT_STREAM_LD(Q.l_shape[sample]), org_tri = RT_STREAM_LD(Q.l_tri[sample]), shape0 = RT_STREAM_LD(Q.occ_shape[k]);
     const float t0 = 1.0f;  // Hit::to_light; a sample whose own primitive blocks the light is not traced at all
-    const double px = RT_STREAM_LD(Q.l_p[0][sample]), py = RT_STREAM_LD(Q.l_p[1][sample]), pz = RT_STREAM_LD(Q.l_p[2][sample]);
+    const D3 p = lit_load_vec(Q.l_p, sample, Q.lit_f32 != 0u);
     const RtLight &light = S.lights[S.point_lights[light_slot]];
     r.org_shape = org_shape;
     r.org_tri = org_tri;
     r.t0 = t0;
     r.shape0 = shape0;
-    r.o = D3{px, py, pz};
+    r.o = p;
     r.d = d3(light.position) - r.o;
     return org_shape >= 0 && shape0 < 0;
 }
@@ -480,7 +482,7 @@ RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint
 // light k (in scene order among the point lights) is hidden.
 template <bool F32>
 RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, uint32_t blocked) {
-    const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+    const D3 p = lit_load_vec(Q.l_p, sample, F32);
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
     const D3 n = lit_load_vec(Q.l_n, sample, F32);
     const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, F32) : D3{0.0, 0.0, -1.0};
@@ -502,10 +504,10 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
                            uint32_t sample) {
     const int32_t shape = Q.l_shape[sample];
     if (shape < 0) return false;
-    const D3 p = D3{RT_STREAM_LD(Q.l_p[0][sample]), RT_STREAM_LD(Q.l_p[1][sample]), RT_STREAM_LD(Q.l_p[2][sample])};
+    const D3 p = lit_load_vec(Q.l_p, sample, Q.lit_f32 != 0u);
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
-    const D3 n = lit_load_vec(Q.l_n, sample, B.light_sums_f32 != 0u);
-    const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, B.light_sums_f32 != 0u) : D3{0.0, 0.0, -1.0};
+    const D3 n = lit_load_vec(Q.l_n, sample, Q.lit_f32 != 0u);
+    const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, Q.lit_f32 != 0u) : D3{0.0, 0.0, -1.0};
     const bool want_ids = ids.shadow_shape || ids.shadow_tri;
     const size_t gs = want_ids ? global_sample(B, sample) : 0;
     ColorF color = {0.0f, 0.0f, 0.0f};

@@ -163,6 +163,7 @@ void run(const HostScene &hs, const RtScene &scene, const RtRenderArgs &args, fl
     Q.lit_list = grab<uint32_t>(pool, 1);
     std::memset(Q.counters, 0, RT_CNT_SIZE * sizeof(uint32_t));
     Q.capacity = cap;
+    Q.lit_f32 = args.mode == RT_MODE_REFERENCE_ORDER ? 0u : 1u;  // as rt::render_frame sets it
 
     RtBatch B{};
     B.tile_list = tile_list.data();
