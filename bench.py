@@ -529,7 +529,9 @@ def main():
             "config": {"workload": desc, "traversal": args.mode,
                        "value_is": "frames delivered to page-locked host memory (what render() returns, render.rs:7-23), "
                                    f"{FLIGHTS} frames in flight",
-                       "precision": "fp32 tree search, f64 hit refinement and shading, f32 colour (as the reference's f64 geometry / f32 colour)",
+                       "precision": ("fp32 tree search, f64 hit refinement (point, normal, mirror direction, self-hit tests), "
+                                     + ("light sums in f32 on the f32-rounded vectors (fast mode), " if args.mode == "fast" else "f64 light sums, ")
+                                     + "f32 colour (the reference: f64 geometry, f32 colour)"),
                        "tile": tile, "tiles": tiles_total,
                        "rays_per_step": total_rays / args.steps, "parallelism": f"tiles/{world}",
                        "part0_weight": part0_weight, "frames_in_flight": FLIGHTS, "hw_queues": int(hw_queues) if hw_queues else "runtime default",
