@@ -211,6 +211,15 @@ def main():
     part0_weight = int(os.environ.get("RT_BENCH_PART0_WEIGHT", "0"))
     rargs = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight,
                             flags=args.render_flags)
+    # The parts of a frame do not cost the same (the bunny frame cut in eight: 0.148-0.162 ms, the dearest
+    # part holds most of a silhouette), and a fixed assignment makes every frame wait for the same GPU.
+    # So the parts ROTATE over the ranks from frame to frame: rank r renders part (r + k) mod N of frame k,
+    # and over N frames every rank has rendered every part once.  A backend caches the tile list of its
+    # part, so each flight keeps one part: flight b renders the frames k = b (mod FLIGHTS), which all have
+    # the same part on this rank when N divides FLIGHTS; otherwise the parts stay where they are.
+    rotate_parts = world > 1 and FLIGHTS % world == 0 and part0_weight == 0
+    flight_args = [dev.render_args(n, mode=mode, tile=(tile, tile), part=((rank + b) % world if rotate_parts else rank, world),
+                                   part0_weight=part0_weight, flags=args.render_flags) for b in range(FLIGHTS)]
     tiles_total, tiles_owned, stride = dev.partition_info(rargs)
     tile_floats = tile * tile * 3
     fb_floats = W * H * 3
@@ -315,8 +324,11 @@ def main():
                         slot = rt.Comm.frame_blocks(world, SLOTS, f, first_root)[2]
                         o = frames_rooted[0] & 1
                         frames_rooted[0] += 1
-                        # rank r's part of the frame lies at block r * SLOTS + slot
-                        dev.untile_device(rargs, gathered[g].data_ptr() + slot * part_floats * 4, fb[o].data_ptr(),
+                        # rank r's part of the frame lies at block r * SLOTS + slot, and it is part (r + f) mod N
+                        # when the parts rotate (frame f of a group ran on flight f mod FLIGHTS)
+                        ua = dev.render_args(n, mode=mode, tile=(tile, tile), part=(rank, world), part0_weight=part0_weight,
+                                             part_rotation=(f % FLIGHTS) % world if rotate_parts else 0)
+                        dev.untile_device(ua, gathered[g].data_ptr() + slot * part_floats * 4, fb[o].data_ptr(),
                                           stream=side.cuda_stream, part_pitch_floats=SLOTS * part_floats)
                         host_fb[o].copy_(fb[o], non_blocking=True)
                         last_delivered[0] = host_fb[o]
@@ -330,8 +342,8 @@ def main():
             with torch.cuda.stream(streams[b]):
                 if sent[g] is not None:
                     streams[b].wait_event(sent[g])  # the exchange of two groups ago has released part[g]
-                st = devs[b].render_device(rargs, part[g].data_ptr() + block * part_floats * 4, stream=streams[b].cuda_stream,
-                                           want_stats=want_stats)
+                st = devs[b].render_device(flight_args[b], part[g].data_ptr() + block * part_floats * 4,
+                                           stream=streams[b].cuda_stream, want_stats=want_stats)
             if f == GROUP - 1:
                 flush(g, GROUP)
             return st
@@ -540,6 +552,9 @@ def main():
                                   "host memory over gloo (one-GPU rehearsal)" if staged else
                                   f"rt_comm_gather_frames: groups of {GROUP} frames, one grouped ncclSend / ncclRecv exchange per group "
                                   "on the library's RCCL communicator, frame k gathered to rank k mod N"),
+                       "parts": ("one (whole frames)" if world == 1 else
+                                 "rotating: rank r renders part (r + k) mod N of frame k" if rotate_parts else
+                                 "fixed: rank r renders part r"),
                        "render_flags": args.render_flags,
                        "scene_upload_ms": upload_s * 1e3,
                        "kernel_split_from": "last warm-up frame (fully instrumented, every kernel alone on the GPU)"},

@@ -175,7 +175,11 @@ typedef struct RtRenderArgs {
     uint32_t batch_samples;
     uint32_t xcd_chunk;
     uint32_t flags;
-    uint32_t _reserved;
+    /* rt_untile_device(_pitched) only, with part_count > 1: block b of the gathered buffer holds the tiles
+     * of part (b + part_rotation) % part_count (0: block p holds part p).  For a stream of frames whose
+     * parts rotate over the GPUs -- GPU r renders part (r + k) % N of frame k -- so that a part that costs
+     * more than the others does not always fall on the same GPU. */
+    uint32_t part_rotation;
 } RtRenderArgs;
 
 enum {

@@ -203,7 +203,7 @@ pub struct RtRenderArgs {
     pub batch_samples: u32,
     pub xcd_chunk: u32,
     pub flags: u32,
-    pub _reserved: u32,
+    pub part_rotation: u32,
 }
 
 impl RtRenderArgs {
@@ -225,7 +225,7 @@ impl RtRenderArgs {
             batch_samples: 0,
             xcd_chunk: 0,
             flags: 0,
-            _reserved: 0,
+            part_rotation: 0,
         }
     }
 }

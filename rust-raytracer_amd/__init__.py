@@ -180,7 +180,7 @@ class RtRenderArgs(C.Structure):
         ("batch_samples", C.c_uint32),
         ("xcd_chunk", C.c_uint32),
         ("flags", C.c_uint32),
-        ("_reserved", C.c_uint32),
+        ("part_rotation", C.c_uint32),
     ]
 
 
@@ -635,9 +635,11 @@ class DeviceScene:
             pass
 
     def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
-                    tile=(0, 0), part=(0, 1), seed=0, part0_weight=0, batch_samples=0, xcd_chunk=0, flags=0) -> RtRenderArgs:
+                    tile=(0, 0), part=(0, 1), seed=0, part0_weight=0, batch_samples=0, xcd_chunk=0, flags=0,
+                    part_rotation=0) -> RtRenderArgs:
         a = RtRenderArgs()
         a.batch_samples, a.xcd_chunk, a.flags = int(batch_samples), int(xcd_chunk), int(flags)
+        a.part_rotation = int(part_rotation)
         a.sqrt_rays_per_pixel = int(sqrt_rays_per_pixel)
         a.antialias_method = int(antialias_method)
         a.mode = int(mode)

@@ -447,13 +447,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_fill_i32(int32_t *p, size_t n, int
 #define RT_UNTILE_BLOCK 64
 __global__ void __launch_bounds__(RT_UNTILE_BLOCK)
 k_untile(const float *gathered, size_t pitch, float *fb, const uint32_t *tile_where, uint32_t width, uint32_t height,
-         uint32_t tw, uint32_t th, uint32_t tiles_x) {
+         uint32_t tw, uint32_t th, uint32_t tiles_x, uint32_t parts, uint32_t unrotate) {
     const uint32_t n_px = width * height;
     for (uint32_t px = blockIdx.x * RT_UNTILE_BLOCK + threadIdx.x; px < n_px; px += gridDim.x * RT_UNTILE_BLOCK) {
         const uint32_t i = px % width, j = px / width;
         const uint32_t tile = (j / th) * tiles_x + i / tw;
         const uint32_t where = tile_where[tile];
-        const size_t src = (size_t)(where >> 20) * pitch + ((size_t)(where & 0xfffffu) * tw * th + (size_t)(j % th) * tw + i % tw) * 3;
+        uint32_t block = (where >> 20) + unrotate;  // part p lies in block (p - rotation) mod parts
+        block = block >= parts ? block - parts : block;
+        const size_t src = (size_t)block * pitch + ((size_t)(where & 0xfffffu) * tw * th + (size_t)(j % th) * tw + i % tw) * 3;
         fb[(size_t)px * 3 + 0] = gathered[src + 0];
         fb[(size_t)px * 3 + 1] = gathered[src + 1];
         fb[(size_t)px * 3 + 2] = gathered[src + 2];
@@ -1335,6 +1337,7 @@ extern "C" int rt_untile_device_pitched(RtBackend *be, uint32_t width, uint32_t 
     if (part_pitch_floats == 0) part_pitch_floats = block_floats;  // end to end
     if (part_pitch_floats < block_floats) return rt::set_error(RT_ERR_INVALID, "part pitch smaller than a part's block of tiles");
     if (parts > 4096 || stride >= (1u << 20)) return rt::set_error(RT_ERR_INVALID, "too many parts or tiles per part for the un-tile table");
+    if (args->part_rotation >= parts) return rt::set_error(RT_ERR_INVALID, "part_rotation must be below part_count");
     RT_HIP(hipSetDevice(be->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : be->stream;
     const uint32_t key[5] = {width, height, tw, th, parts | (args->part0_weight << 24)};
@@ -1354,7 +1357,8 @@ extern "C" int rt_untile_device_pitched(RtBackend *be, uint32_t width, uint32_t 
     }
     const uint64_t untile_blocks = ((uint64_t)width * height + RT_UNTILE_BLOCK - 1) / RT_UNTILE_BLOCK;
     hipLaunchKernelGGL(k_untile, dim3((uint32_t)std::min<uint64_t>(untile_blocks, 4u * RT_MAX_GRID)), dim3(RT_UNTILE_BLOCK), 0, stream,
-                       gathered_dev, part_pitch_floats, fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x);
+                       gathered_dev, part_pitch_floats, fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x, parts,
+                       (parts - args->part_rotation) % parts);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -726,7 +726,16 @@ def test_bench_launches_its_own_ranks_and_rotates_the_root(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 3 and line["config"]["rccl_ranks"] == 3 and line["steps"] == 20
+    assert line["config"]["parts"].startswith("fixed")  # three ranks do not divide four frames in flight
     assert "bit-identical" in line["config"]["frame_check"] and "each of the 3 ranks" in line["config"]["frame_check"]
+    # two ranks: the number of ranks divides the frames in flight, so the parts also rotate over the ranks
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+                          "--no-cpu-baseline", "--workload", "spheres_and_triangles"], env=env, capture_output=True, text=True,
+                         timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parts"].startswith("rotating")
+    assert "bit-identical" in line["config"]["frame_check"] and "each of the 2 ranks" in line["config"]["frame_check"]
 
 
 def test_comm_gather_frames_with_one_rank(rt, backend, scene_path):
@@ -773,4 +782,39 @@ def test_comm_gather_frames_with_one_rank(rt, backend, scene_path):
     with pytest.raises(rt.RtError):
         comm.gather_frames(send.data_ptr(), block, 1, 1, slots, recv.data_ptr(), stream=st.cuda_stream)
     comm.close()
+    dev.close()
+
+
+def test_untile_with_rotated_parts(rt, backend, scene_path):
+    """RtRenderArgs.part_rotation: block b of the gathered buffer holds part (b + rotation) mod N -- what a root
+    receives when the parts rotate over the ranks from frame to frame.  Un-tiling must give the frame
+    rendered whole for every rotation, and a rotation out of range is refused."""
+    import torch
+
+    W, H, tile, parts = 250, 170, 16, 3
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    whole, _, _ = dev.render(2)
+    a = dev.render_args(2, tile=(tile, tile), part=(0, parts))
+    _, _, stride = dev.partition_info(a)
+    block = stride * tile * tile * 3
+    st = torch.cuda.Stream()
+    gathered = torch.zeros(parts * block, dtype=torch.float32, device="cuda")
+    fb = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for rot in range(parts):
+        gathered.fill_(-1.0)
+        fb.zero_()
+        torch.cuda.synchronize()
+        for b in range(parts):  # block b <- part (b + rot) mod parts
+            ap = dev.render_args(2, tile=(tile, tile), part=((b + rot) % parts, parts))
+            dev.render_device(ap, gathered.data_ptr() + b * block * 4, stream=st.cuda_stream)
+        dev.untile_device(dev.render_args(2, tile=(tile, tile), part=(0, parts), part_rotation=rot), gathered.data_ptr(),
+                          fb.data_ptr(), stream=st.cuda_stream)
+        backend.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(fb.cpu().numpy().reshape(H, W, 3), whole.pixels), rot
+    with pytest.raises(rt.RtError):
+        dev.untile_device(dev.render_args(2, tile=(tile, tile), part=(0, parts), part_rotation=parts), gathered.data_ptr(),
+                          fb.data_ptr(), stream=st.cuda_stream)
     dev.close()
