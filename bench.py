@@ -287,11 +287,37 @@ def main():
         last_delivered = [None]          # the host buffer that holds the newest frame this rank was root of
         frames_sent = [0]                # frames handed to an exchange so far: the next group's first root follows from it
         frames_rooted = [0]
+        exchange_by = "gloo" if staged else "library"
         if not staged:
-            # the library's own RCCL communicator: rank 0 makes the id, the launcher's process group carries it
-            ids = [rt.Comm.make_id() if rank == 0 else None]
+            # The library's own RCCL communicator: rank 0 makes the id, the launcher's process group carries
+            # it.  Should that communicator not come up on some node (a second copy of librccl in the process,
+            # a bootstrap problem), every rank falls back to the SAME exchange posted through torch.distributed
+            # -- one send per (rank, root) pair, one receive each, in one batch -- and the line says so: a
+            # scaling figure with a flag is worth more than none.  RT_BENCH_EXCHANGE=torch forces the fallback.
+            failed = 0
+            try:
+                if os.environ.get("RT_BENCH_EXCHANGE", "library") == "torch":
+                    raise rt.RtError(-4, "RT_BENCH_EXCHANGE=torch")
+                ids = [rt.Comm.make_id() if rank == 0 else None]
+            except rt.RtError as e:
+                ids, failed = [None], 1
+                print(f"[bench rank {rank}] rt_comm_id failed: {e}", file=sys.stderr)
             dist.broadcast_object_list(ids, src=0)
-            comm = rt.Comm(backends[0], ids[0], rank, world)
+            if ids[0] is not None and not failed:
+                try:
+                    comm = rt.Comm(backends[0], ids[0], rank, world)
+                except rt.RtError as e:
+                    failed = 1
+                    print(f"[bench rank {rank}] rt_comm_create failed: {e}", file=sys.stderr)
+            else:
+                failed = 1
+            agreed = torch.tensor([failed], dtype=torch.int32, device="cuda")
+            dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+            if int(agreed.item()):
+                if comm is not None:
+                    comm.close()
+                comm = None
+                exchange_by = "torch"
 
         def flush(g, count):
             """Exchanges the first `count` frames of group g; this rank un-tiles and copies out those it is root of."""
@@ -312,9 +338,22 @@ def main():
                         if rank == root_rank:
                             for r in range(world):
                                 gathered[g][r * SLOTS * part_floats: (r * SLOTS + k) * part_floats].copy_(bufs[r])
-                else:
+                elif comm is not None:
                     comm.gather_frames(part[g].data_ptr(), part_floats, count, first_root, SLOTS, gathered[g].data_ptr(),
                                        stream=joiner.cuda_stream)
+                else:  # the fallback: rt_comm_gather_frames' sends and receives through torch.distributed
+                    ops = []
+                    for p in range(min(count, world)):
+                        k = -(-(count - p) // world)
+                        ops.append(dist.P2POp(dist.isend, part[g][p * SLOTS * part_floats: (p * SLOTS + k) * part_floats],
+                                              (first_root + p) % world))
+                    my_p = (rank - first_root) % world
+                    if my_p < count:
+                        k = -(-(count - my_p) // world)
+                        for r in range(world):
+                            ops.append(dist.P2POp(dist.irecv, gathered[g][r * SLOTS * part_floats: (r * SLOTS + k) * part_floats], r))
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()  # (orders the current stream behind the transfer; the host does not block)
                 sent[g] = joiner.record_event()
             mine = [f for f in range(count) if rt.Comm.frame_blocks(world, SLOTS, f, first_root)[0] == rank]
             if mine:
@@ -550,6 +589,8 @@ def main():
                        "rccl_ranks": dist.get_world_size() if multi else 1,
                        "gather": ("none (one GPU)" if not multi else
                                   "host memory over gloo (one-GPU rehearsal)" if staged else
+                                  "FALLBACK: the library's communicator did not come up; the same sends and receives "
+                                  "through torch.distributed (batch_isend_irecv)" if exchange_by == "torch" else
                                   f"rt_comm_gather_frames: groups of {GROUP} frames, one grouped ncclSend / ncclRecv exchange per group "
                                   "on the library's RCCL communicator, frame k gathered to rank k mod N"),
                        "parts": ("one (whole frames)" if world == 1 else

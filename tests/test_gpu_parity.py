@@ -704,6 +704,14 @@ def test_bench_multi_gpu_path_with_one_rank(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 1e9
     assert "rt_comm_gather" in line["config"]["gather"]
+    # the harness's fallback for a node on which the library's communicator does not come up: the same sends
+    # and receives through torch.distributed, flagged in the line
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "2",
+                          "--no-cpu-baseline", "--workload", "spheres_and_triangles"], env=dict(env, RT_BENCH_EXCHANGE="torch"),
+                         capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["gather"].startswith("FALLBACK") and line["value"] > 1e9
 
 
 def test_bench_launches_its_own_ranks_and_rotates_the_root(tmp_path):
