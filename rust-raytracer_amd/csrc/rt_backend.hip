@@ -33,17 +33,18 @@
 //   packets   8 waves (64 VGPRs, 36..48 B of scratch in the scene-level primitive code): bunny frame
 //             camera rays 0.326 -> 0.312 ms, shadow rays 0.794 -> 0.736 ms; 7 waves lies in between
 //   shade     behind camera rays (k_shade<true>, no loop, no queue code): 6 waves (79 VGPRs, 12 B of scratch),
-//             bunny frame 0.318 -> 0.253 ms (5 waves: 0.267); behind mirror bounces (k_shade<false>): 4 waves
-//             (125 VGPRs, no scratch; 5 waves spill 108 B inside the f64 code)
-//   shadow rays + light sums in one kernel: 7 waves (72 VGPRs); at 8 the f64 light sums spill 64 B and the
-//             frame is 2 % slower than with separate kernels, at 7 it is as fast (bunny, 2 lights) or
-//             7 % faster (spheres_1K, 4 lights)
+//             bunny frame 0.318 -> 0.253 ms (5 waves: 0.267); behind mirror bounces (k_shade<false>): 6 waves
+//             too (78 VGPRs, no scratch) since it covers the queue with its grid instead of striding over it
+//             in a loop, which alone took 125 registers (cornell_room: 0.555 -> 0.538 ms over its six launches)
+//   shadow rays + light sums in one kernel: 7 waves (72 VGPRs); at 8 it spills 24 B and the frame is 5 %
+//             slower, at 7 it is as fast as separate kernels (bunny, 2 lights) or 7 % faster (spheres_1K,
+//             4 lights)
 //   accumulate 8 waves (60 VGPRs, no scratch; 76 without the hint): 0.195 -> 0.183 ms
 #define RT_PACKET_WAVES 8
 #ifndef RT_FUSED_WAVES
 #define RT_FUSED_WAVES 7
 #endif
-#define RT_SHADE_WAVES 4
+#define RT_SHADE_WAVES 6
 #ifndef RT_SHADE_FIRST_WAVES
 #define RT_SHADE_FIRST_WAVES 6
 #endif
@@ -124,16 +125,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(RtSceneView S, RtBuf
         trace_closest_body<LdsStack, ORDERED, EXACT>(S, Q, B, bounce, idx, stk);
 }
 
-// FIRST: the stage behind the camera rays (bounce 0), launched with one thread per sample: no loop, no
-// queue to read, and the compiler folds every "bounce == 0 ?" of the stage body.  Otherwise a fixed
-// grid strides over the queue of mirror rays, whose length only the device knows.
+// FIRST: the stage behind the camera rays (bounce 0), launched with one thread per sample: no queue to
+// read, and the compiler folds every "bounce == 0 ?" of the stage body.  Otherwise the grid covers the
+// longest queue of mirror rays there can be (its length only the device knows) and the blocks beyond
+// the queue's end leave at once.
 template <bool FIRST>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(FIRST ? RT_SHADE_FIRST_WAVES : RT_SHADE_WAVES, FIRST ? RT_SHADE_FIRST_WAVES : RT_SHADE_WAVES)))
 k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce_arg, uint32_t n_samples) {
     const int bounce = FIRST ? 0 : bounce_arg;
     const uint32_t count = FIRST ? n_samples : Q.counters[RT_CNT_RAYS0 + bounce];
-    const uint32_t stride = FIRST ? 0xffffffffu - RT_BLOCK : gridDim.x * RT_BLOCK;
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < count; base += stride) {
+    {
+        const uint32_t base = blockIdx.x * RT_BLOCK;
+        if (base >= count) return;  // the grid covers the longest queue there can be
         const uint32_t idx = base + threadIdx.x;
         MirrorTmp tmp;
         const int act = idx < count ? shade_classify(S, Q, B, ids, bounce, idx, tmp) : RT_ACT_NONE;
@@ -158,7 +161,6 @@ k_shade(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, int bounce_arg, uint
                 todo &= ~same;
             }
         }
-        if (FIRST) break;
     }
 }
 
@@ -895,7 +897,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (bounce == 0)
                 hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, 0, n_samples);
             else
-                hipLaunchKernelGGL((k_shade<false>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
+                hipLaunchKernelGGL((k_shade<false>), dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
             tm.end();
         }
         if (ds->has_lit) {
