@@ -133,19 +133,24 @@ RT_HD D3 transform_point(const double *m, const D3 &p) {
 // ---------------------------------------------------------------- f64 "exact" primitives
 
 // BBox::hit, geometry/bbox.rs:76-125, sequential form.
+// The reference swaps a slab's two distances when 1 / d < 0 (bbox.rs:84).  That quotient is negative exactly
+// when d carries a sign bit and is not NaN (1 / -0.0 = -inf included), so it is read off d: the same
+// decisions, three divisions less per call.
+RT_HD bool rt_inv_negative(double d) { return __builtin_signbit(d) && d == d; }
+
 RT_HD bool slab_f64(const D3 &mn, const D3 &mx, const D3 &o, const D3 &d, double tmin, double tmax, double &t_out) {
     double tn = (mn.x - o.x) / d.x, tf = (mx.x - o.x) / d.x;
-    if (1.0 / d.x < 0.0) { double s = tn; tn = tf; tf = s; }
+    if (rt_inv_negative(d.x)) { double s = tn; tn = tf; tf = s; }
     if (tn >= tf || tn >= tmax || tf <= tmin) return false;
     tmax = rt_dmin(tmax, tf);
     tmin = rt_dmax(tmin, tn);
     tn = (mn.y - o.y) / d.y; tf = (mx.y - o.y) / d.y;
-    if (1.0 / d.y < 0.0) { double s = tn; tn = tf; tf = s; }
+    if (rt_inv_negative(d.y)) { double s = tn; tn = tf; tf = s; }
     if (tn >= tf || tn >= tmax || tf <= tmin) return false;
     tmax = rt_dmin(tmax, tf);
     tmin = rt_dmax(tmin, tn);
     tn = (mn.z - o.z) / d.z; tf = (mx.z - o.z) / d.z;
-    if (1.0 / d.z < 0.0) { double s = tn; tn = tf; tf = s; }
+    if (rt_inv_negative(d.z)) { double s = tn; tn = tf; tf = s; }
     if (tn >= tf || tn >= tmax || tf <= tmin) return false;
     t_out = rt_dmax(tn, tmin);
     return true;
@@ -238,7 +243,8 @@ RT_HD bool exact_prim_hit(const RtSceneView &S, int32_t shape_id, int32_t gtri, 
             t = t_fallback;
             got = true;
         }
-        if (got && normal_out) n = normalize(cuboid_normal(mn, mx, o + d * t));  // cuboid.rs:66
+        // cuboid.rs:66 normalises this axis vector: a division of +-1 and 0 by sqrt(1.0) = 1.0, which changes no bit
+        if (got && normal_out) n = cuboid_normal(mn, mx, o + d * t);
         break;
     }
     case RT_SHAPE_TRIANGLE: {
@@ -887,14 +893,27 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
 // around t = 0, far below t_min) and the test is skipped.  A box is always tested: for a ray
 // that started inside it the reference reports the "hit" at t_min, a point INSIDE the box
 // (cuboid.rs:63-73 with bbox.rs:124), from which every direction hits the box again.
+//
+// `box_leaves`: the caller has found the ray to leave the surface by a clear margin (leaves_clearly below)
+// and the mode allows conclusions in place of arithmetic.  The hit point lies on a face of the box to within
+// a few units in the last place (2e-15 for coordinates of order 10), the box is convex, so such a ray is out of
+// it again at t <= 2e-15 / (n . d): below t_min = 1e-6 whenever the cosine exceeds 2e-9, and the reference's
+// slab test -- two divisions per axis, once per light -- would report no hit.
 RT_HD bool self_hit_f64(const RtSceneView &S, int32_t org_shape, const D3 &o, const D3 &d, double tmin, double tmax,
-                        bool outward, double &t_out) {
+                        bool outward, bool box_leaves, double &t_out) {
     if (org_shape < 0) return false;
     const RtShape *sh = &S.shapes[org_shape];
     const int32_t pt = sh->type == RT_SHAPE_INSTANCE ? S.protos[sh->proto].type : sh->type;
     if (pt != RT_SHAPE_SPHERE && pt != RT_SHAPE_BOX) return false;
     if (pt == RT_SHAPE_SPHERE && outward) return false;
+    if (pt == RT_SHAPE_BOX && box_leaves) return false;
     return exact_prim_hit(S, org_shape, -1, o, d, tmin, tmax, false, 0.0, t_out, nullptr);
+}
+
+// The ray from a surface point along `d` leaves on the side of the unit normal `n` with a cosine above 1e-6.
+RT_HD bool leaves_clearly(const D3 &n, const D3 &d) {
+    const double nd = dot(n, d);
+    return nd > 0.0 && nd * nd > 1e-12 * dot(d, d);
 }
 
 // ---------------------------------------------------------------- camera

@@ -329,6 +329,9 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
     D3 n;
     exact_prim_hit(S, shape, gtri, o, d, tmin, (double)__builtin_inff(), true, t, t, &n);
     const D3 p = o + d * t;  // Hit::hit_point, hit_struct.rs:41-43
+    // Fast mode only: p is known to lie ON the primitive (self_hit_f64's box_leaves).  Not so when the ray
+    // started inside a box: the reference then reports the hit at t_min (bbox.rs:124), a point inside it.
+    const bool on_surface = Q.lit_f32 != 0u && t > tmin;
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
     switch (sh.type) {
     case RT_SHADER_LAMBERTIAN:
@@ -344,7 +347,8 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
             for (int ls = 0; ls < S.n_point_lights; ++ls) {
                 const D3 dir = d3(S.lights[S.point_lights[ls]].position) - p;  // Ray::atob, ray.rs:15-20
                 double st = 0.0;
-                const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, st);
+                const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0,
+                                               on_surface && leaves_clearly(n, dir), st);
                 if (B.fused_shadows) {
                     self_mask |= self ? 1u << (ls & 31) : 0u;
                     continue;
@@ -372,7 +376,7 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         tmp.tri = gtri;
         double st;
         tmp.self_t = self_hit_f64(S, shape, tmp.p, tmp.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(),
-                                  dot(n, tmp.d) > 0.0, st)
+                                  dot(n, tmp.d) > 0.0, on_surface && leaves_clearly(n, tmp.d), st)
                          ? (float)st
                          : __builtin_inff();
         return RT_ACT_MIRROR;

@@ -99,7 +99,7 @@ RT_HD ColorF tree_shade_lights(const RtSceneView &S, Stack &stk, const RtShader 
         if (!S.disable_shadows) {
             counts.shadow += 1;
             double st = 0.0;
-            const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, st);
+            const bool self = self_hit_f64(S, shape, p, dir, RT_VERY_SMALL_NUMBER, 1.0, dot(n, dir) > 0.0, false, st);
             float t;
             int32_t bs, bt;
             ok = tree_trace<Stack, FAST>(S, stk, p, dir, (float)RT_VERY_SMALL_NUMBER, 1.0f, true,
@@ -178,7 +178,7 @@ RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t 
                     org_shape = shape;
                     org_tri = gtri;
                     double st;
-                    self_t = self_hit_f64(S, shape, o, d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(n, d) > 0.0, st)
+                    self_t = self_hit_f64(S, shape, o, d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(n, d) > 0.0, false, st)
                                  ? (float)st
                                  : __builtin_inff();
                     counts.secondary += 1;
@@ -217,7 +217,7 @@ RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t 
             org_shape = f.shape;
             org_tri = f.tri;
             double st;
-            self_t = self_hit_f64(S, f.shape, o, d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(f.n, d) > 0.0, st)
+            self_t = self_hit_f64(S, f.shape, o, d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(f.n, d) > 0.0, false, st)
                          ? (float)st
                          : __builtin_inff();
             counts.secondary += 1;

@@ -361,7 +361,7 @@ extern "C" int hostsim_trace_rays_from(const RtScene *scene, uint64_t n, const d
         hit.shape = -1;
         hit.tri = -1;
         double st;
-        if (self_hit_f64(hs.view, os, ro, rd, tmin[r], tmax[r], false, st)) {  // direction unknown here: always test
+        if (self_hit_f64(hs.view, os, ro, rd, tmin[r], tmax[r], false, false, st)) {  // direction unknown here: always test
             hit.t = (float)st;
             hit.shape = os;
         }
