@@ -236,29 +236,46 @@ void triangle_map(const double *v, RtTriXf &out) {
 
 // Emits the subtree `t` of `tree` into out.nodes and returns the reference a
 // parent stores for it.  `prim_base` is added to leaf offsets.
-int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0) {
+//
+// `larger_left` (the fast mode's trees only; the reference's trees keep the reference's child order): the child
+// with the larger surface goes into the left slot.  Any-hit packets visit the left child first whatever the
+// direction of their rays, and a shadow ray that is blocked at all is more likely to be blocked in the larger
+// of two boxes.  Closest-hit traversal is unaffected: it goes by right_first_mask, which is mirrored with
+// the children.
+int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0,
+             bool larger_left = false) {
     const TreeNode &n = tree.nodes[(size_t)t];
     if (n.count > 0) return rt_make_leaf_ref(prim_base + n.first, n.count);
     const int32_t me = (int32_t)nodes.size();
     nodes.emplace_back();
-    const TreeNode &l = tree.nodes[(size_t)n.left];
-    const TreeNode &r = tree.nodes[(size_t)n.right];
+    auto half_area = [](const TreeNode &c) {
+        const double x = c.bmax[0] - c.bmin[0], y = c.bmax[1] - c.bmin[1], z = c.bmax[2] - c.bmin[2];
+        return x * y + y * z + z * x;
+    };
+    const bool swap = larger_left && half_area(tree.nodes[(size_t)n.right]) > half_area(tree.nodes[(size_t)n.left]);
+    const int32_t li = swap ? n.right : n.left, ri = swap ? n.left : n.right;
+    const TreeNode &l = tree.nodes[(size_t)li];
+    const TreeNode &r = tree.nodes[(size_t)ri];
     RtNode rec{};
     set_child_box(rec, false, l.bmin, l.bmax, flat_pad);
     set_child_box(rec, true, r.bmin, r.bmax, flat_pad);
     nodes[(size_t)me] = rec;
-    const int32_t lref = emit(tree, n.left, prim_base, nodes, flat_pad);
-    const int32_t rref = emit(tree, n.right, prim_base, nodes, flat_pad);
+    const int32_t lref = emit(tree, li, prim_base, nodes, flat_pad, larger_left);
+    const int32_t rref = emit(tree, ri, prim_base, nodes, flat_pad, larger_left);
     nodes[(size_t)me].left = lref;
     nodes[(size_t)me].right = rref;
     nodes[(size_t)me].axis = n.axis;
-    nodes[(size_t)me].right_first_mask = n.axis == 0 ? 0xAA : (n.axis == 1 ? 0xCC : 0xF0);
+    // the builders put the smaller centroids into n.left: a ray that runs towards smaller coordinates on the
+    // split axis reaches n.right first
+    const int32_t right_first = n.axis == 0 ? 0xAA : (n.axis == 1 ? 0xCC : 0xF0);
+    nodes[(size_t)me].right_first_mask = swap ? (right_first ^ 0xFF) : right_first;
     return me * (int32_t)sizeof(RtNode);
 }
 
 // Header node: its left child is the tree's root (with the root's own box, which
 // the reference tests on entry, bvh.rs:95), its right child is absent.
-int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0) {
+int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0,
+                         bool larger_left = false) {
     const int32_t header = (int32_t)nodes.size();
     nodes.emplace_back();
     RtNode rec{};
@@ -268,7 +285,7 @@ int32_t emit_with_header(const Tree &tree, uint32_t prim_base, std::vector<RtNod
     rec.rx[0] = rec.rx[1] = rec.ry[0] = rec.ry[1] = rec.rz[0] = rec.rz[1] = 0.0f;
     rec.right = RT_REF_NONE;
     nodes[(size_t)header] = rec;
-    const int32_t root_ref = emit(tree, 0, prim_base, nodes, flat_pad);
+    const int32_t root_ref = emit(tree, 0, prim_base, nodes, flat_pad, larger_left);
     nodes[(size_t)header].left = root_ref;
     return header * (int32_t)sizeof(RtNode);
 }
@@ -488,7 +505,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out, bool reference_m
     // ---- node array: scene-level tree first, then the meshes
     out.tlas_root = emit_with_header(out.tlas, 0, out.nodes);
     const uint32_t fast_base = (uint32_t)out.tlas.order.size();  // the fast tree's primitives follow the reference tree's
-    out.tlas_root_fast = own_fast_tree ? emit_with_header(out.tlas_fast, fast_base, out.nodes, flat_pad) : out.tlas_root;
+    out.tlas_root_fast = own_fast_tree ? emit_with_header(out.tlas_fast, fast_base, out.nodes, flat_pad, true) : out.tlas_root;
     std::vector<int32_t> blas_root(scene.n_meshes), blas_root_fast(scene.n_meshes);
     int blas_depth = 0, blas_depth_fast = 0;
     for (uint32_t m = 0; m < scene.n_meshes; ++m) {
@@ -499,7 +516,7 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out, bool reference_m
         blas_root_fast[m] = blas_root[m];
         blas_depth_fast = std::max(blas_depth_fast, out.blas[m].inner_depth);
         if (!own_fast_tree || out.blas_fast[m].nodes.empty()) continue;  // only the fast scene-level tree's primitives point here
-        blas_root_fast[m] = emit_with_header(out.blas_fast[m], (uint32_t)out.mesh_tri_base_fast[m], out.nodes, mesh_pad[m]);
+        blas_root_fast[m] = emit_with_header(out.blas_fast[m], (uint32_t)out.mesh_tri_base_fast[m], out.nodes, mesh_pad[m], true);
         blas_depth_fast = std::max(blas_depth_fast, out.blas_fast[m].inner_depth);
     }
     // pushes on one path: one per inner node with two live children, plus, when a
