@@ -234,25 +234,28 @@ void triangle_map(const double *v, RtTriXf &out) {
     }
 }
 
+// Items (shapes or triangles) below node `t`.
+uint32_t subtree_items(const Tree &tree, int32_t t) {
+    const TreeNode &n = tree.nodes[(size_t)t];
+    return n.count > 0 ? n.count : subtree_items(tree, n.left) + subtree_items(tree, n.right);
+}
+
 // Emits the subtree `t` of `tree` into out.nodes and returns the reference a
 // parent stores for it.  `prim_base` is added to leaf offsets.
 //
 // `larger_left` (the fast mode's trees only; the reference's trees keep the reference's child order): the child
-// with the larger surface goes into the left slot.  Any-hit packets visit the left child first whatever the
-// direction of their rays, and a shadow ray that is blocked at all is more likely to be blocked in the larger
-// of two boxes.  Closest-hit traversal is unaffected: it goes by right_first_mask, which is mirrored with
-// the children.
+// that holds more items goes into the left slot.  Any-hit packets visit the left child first whatever the
+// direction of their rays, and a shadow ray that is blocked at all is more likely to be blocked where there
+// is more to be blocked by (measured on the bunny frame's shadow kernel: more items first 0.532 ms, larger
+// surface first 0.544, nearer first 0.576).  Closest-hit traversal is unaffected: it goes by
+// right_first_mask, which is mirrored with the children.
 int32_t emit(const Tree &tree, int32_t t, uint32_t prim_base, std::vector<RtNode> &nodes, double flat_pad = 0.0,
              bool larger_left = false) {
     const TreeNode &n = tree.nodes[(size_t)t];
     if (n.count > 0) return rt_make_leaf_ref(prim_base + n.first, n.count);
     const int32_t me = (int32_t)nodes.size();
     nodes.emplace_back();
-    auto half_area = [](const TreeNode &c) {
-        const double x = c.bmax[0] - c.bmin[0], y = c.bmax[1] - c.bmin[1], z = c.bmax[2] - c.bmin[2];
-        return x * y + y * z + z * x;
-    };
-    const bool swap = larger_left && half_area(tree.nodes[(size_t)n.right]) > half_area(tree.nodes[(size_t)n.left]);
+    const bool swap = larger_left && subtree_items(tree, n.right) > subtree_items(tree, n.left);
     const int32_t li = swap ? n.right : n.left, ri = swap ? n.left : n.right;
     const TreeNode &l = tree.nodes[(size_t)li];
     const TreeNode &r = tree.nodes[(size_t)ri];
