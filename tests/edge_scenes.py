@@ -77,12 +77,28 @@ def scenes(tmp_dir):
                    {"_name": "i2", "_type": "instance", "shader": "lam", "_id": "ball",
                     "xform": [{"type": "scale", "amount": "0.4 1.3 0.6"}, {"type": "translate", "amount": "1.4 0 0.5"}]},
                    BALLS[2]], light=[POINT]), 96, 72, 2),
+        # Boxes lit at grazing angles: two lights a hair above the plane of the floor's top face (cosines of 1e-6 and
+        # 1e-8 on that face, either side of the margin below which the shade stage runs the slab test), one well
+        # above; plus an instanced, scaled and rotated box.  (The boxes reach into the floor: faces in one plane
+        # with rays that skim it would make exact ties, which an f32 tree search and the f64 reference break apart.)  The shade stage
+        # decides "can this shadow ray meet its own box again" without the slab test when the ray clearly leaves
+        # the face, and with it otherwise: every answer must be the reference's.
+        "boxes_grazing_lights": (_scene(
+            instance=[{"_name": "unit", "_type": "box", "shader": "lam", "minPt": "-0.5 -0.5 -0.5", "maxPt": "0.5 0.5 0.5"}],
+            shape=[BALLS[2],
+                   {"_name": "crate", "_type": "box", "shader": "bp", "minPt": "-1.6 -1.2 -0.9", "maxPt": "-0.4 0.2 0.3"},
+                   {"_name": "slab", "_type": "instance", "shader": "lam", "_id": "unit",
+                    "xform": [{"type": "scale", "amount": "1.8 0.4 1.1"}, {"type": "rotate", "axis": "Y", "amount": 25},
+                              {"type": "translate", "amount": "1.1 -0.9 0.4"}]}],
+            light=[{"_type": "point", "position": "5.0 -0.99999 2.0", "intensity": "0.6 0.6 0.6"},
+                   {"_type": "point", "position": "-4.0 -0.9999999 3.0", "intensity": "0.5 0.5 0.5"},
+                   POINT]), 96, 72, 2),
     }
     return {k: (json.dumps(v[0]), tmp_dir) + v[1:] for k, v in out.items()}
 
 
 NAMES = ["no_lights", "ambient_only", "one_shape", "one_pixel", "wide_aspect", "odd_size_many_samples", "camera_inside_box",
-         "mirror_pair", "degenerate_mesh", "half_flat_mesh", "scaled_instances"]
+         "mirror_pair", "degenerate_mesh", "half_flat_mesh", "scaled_instances", "boxes_grazing_lights"]
 
 
 def ggx_scene(roughness=0.25, samples=3, mirror_type=None):
