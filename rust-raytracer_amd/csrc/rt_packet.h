@@ -340,6 +340,187 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
 }
 #endif
 
+// A whole mesh tree in one block of assembly: the node walk above, the triangles of every leaf it
+// reaches (the arithmetic of packet_triangle_asm, then the acceptance rules of fast_triangle), the pops
+// in between, and for any-hit packets the test "is any lane still looking" after each leaf.  It returns
+// when it pops the marker that was pushed below the tree's root (RT_REF_EXIT_BLAS), or RT_REF_NONE when an
+// any-hit wave is done.  Between two leaves of one mesh the compiler's code is then not involved at all;
+// with the leaves in C++ it moved the lane's ray (12 registers) out of and back into the registers the
+// walk wants around every leaf, and dispatched on the direction octant again.
+//
+// Acceptance, cheapest first, each step skipped when no lane is left: t >= tmin; gamma >= 0, beta >= 0,
+// t <= bound; beta <= 1 - gamma and "not the triangle the ray starts on".  Lanes that pass take the hit
+// under an exec mask.  s60 = index of the triangle, s61 = triangles left in the leaf, s62 = byte offset
+// of its record; t, beta, gamma in v54..v56.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_BLAS_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER, TAKE_T, LEAF_END)    \
+    "s_cmp_lt_i32 %[cur], 0\n\t"                                                                                         \
+    "s_cbranch_scc1 7f\n"                                                                                                \
+    "1:\n\t"                                                                                                             \
+    "s_load_dwordx8 s[48:55], %[nb], %[cur]\n\t"                                                                         \
+    "s_load_dwordx8 s[56:63], %[nb], %[cur] offset:0x20\n\t"                                                             \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+    "s_nop 0\n\t"                                                                                                        \
+    "v_pk_fma_f32 v[48:49], s[48:49], %[ixy], %[nxy] op_sel_hi:[1,0,0]\n\t"                                              \
+    "v_pk_fma_f32 v[50:51], s[50:51], %[ixy], %[nxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                               \
+    "v_pk_fma_f32 v[52:53], s[56:57], %[zin], %[zin] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                               \
+    "v_pk_fma_f32 v[54:55], s[52:53], %[ixy], %[nxy] op_sel_hi:[1,0,0]\n\t"                                              \
+    "v_pk_fma_f32 v[56:57], s[54:55], %[ixy], %[nxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                               \
+    "v_pk_fma_f32 v[58:59], s[58:59], %[zin], %[zin] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                               \
+    "v_max_f32 v60, " E_LX ", " E_LY "\n\t"                                                                              \
+    "v_min_f32 v61, " X_LX ", " X_LY "\n\t"                                                                              \
+    "v_max3_f32 v60, v60, " E_LZ ", %[tmin]\n\t"                                                                         \
+    "v_min3_f32 v61, v61, " X_LZ ", %[t]\n\t"                                                                            \
+    "v_cmp_lt_f32_e64 s[54:55], v60, v61\n\t"                                                                            \
+    "v_max_f32 v60, " E_RX ", " E_RY "\n\t"                                                                              \
+    "v_min_f32 v61, " X_RX ", " X_RY "\n\t"                                                                              \
+    "v_max3_f32 v60, v60, " E_RZ ", %[tmin]\n\t"                                                                         \
+    "v_min3_f32 v61, v61, " X_RZ ", %[t]\n\t"                                                                            \
+    "v_cmp_lt_f32_e64 s[56:57], v60, v61\n\t"                                                                            \
+    ORDER /* s48 / s49 = first / second child, s[50:51] / s[52:53] = their ballots */                                    \
+    "s_cmp_lg_u64 s[50:51], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 3f\n\t"                                                                                              \
+    "s_mov_b32 %[cur], s48\n\t"                                                                                          \
+    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 5f\n\t"                                                                                              \
+    "s_lshl2_add_u32 s58, %[sp], %[base]\n\t" /* both: push the second */                                                \
+    "v_mov_b32 v60, s58\n\t"                                                                                             \
+    "ds_write_b32 v60, %[tos]\n\t"                                                                                       \
+    "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                      \
+    "s_max_i32 %[high], %[high], %[sp]\n\t"                                                                              \
+    "v_mov_b32 %[tos], s49\n\t"                                                                                          \
+    "s_branch 5f\n"                                                                                                      \
+    "3:\n\t"                                                                                                             \
+    "s_mov_b32 %[cur], s49\n\t"                                                                                          \
+    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 5f\n"                                                                                                \
+    "4:\n\t" /* pop */                                                                                                   \
+    "v_readfirstlane_b32 %[cur], %[tos]\n\t"                                                                             \
+    "s_sub_i32 %[sp], %[sp], 1\n\t"                                                                                      \
+    "s_max_i32 %[sp], %[sp], 0\n\t"                                                                                      \
+    "s_lshl2_add_u32 s58, %[sp], %[base]\n\t"                                                                            \
+    "v_mov_b32 v60, s58\n\t"                                                                                             \
+    "ds_read_b32 %[tos], v60\n"                                                                                          \
+    "5:\n\t"                                                                                                             \
+    "s_cmp_lt_i32 %[cur], 0\n\t"                                                                                         \
+    "s_cbranch_scc0 1b\n"                                                                                                \
+    "7:\n\t" /* a leaf, or one of the two markers (0x80000000, 0x80000001) */                                            \
+    "s_cmp_le_i32 %[cur], 0x80000001\n\t"                                                                                \
+    "s_cbranch_scc1 9f\n\t"                                                                                              \
+    "s_not_b32 s60, %[cur]\n\t"                                                                                          \
+    "s_and_b32 s61, s60, 7\n\t"                                                                                          \
+    "s_lshr_b32 s60, s60, 3\n\t"                                                                                         \
+    "s_mul_i32 s62, s60, 48\n"                                                                                           \
+    "8:\n\t"                                                                                                             \
+    "s_load_dwordx8 s[48:55], %[tb], s62\n\t"                                                                            \
+    "s_load_dwordx4 s[56:59], %[tb], s62 offset:0x20\n\t"                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+    "s_nop 0\n\t"                                                                                                        \
+    "v_pk_mul_f32 v[48:49], %[pz], s[58:59] op_sel_hi:[1,0]\n\t"                                                         \
+    "v_pk_fma_f32 v[48:49], %[py], s[56:57], v[48:49] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                              \
+    "v_pk_fma_f32 v[48:49], %[px], s[56:57], v[48:49] op_sel_hi:[1,0,1]\n\t"                                             \
+    "v_pk_mul_f32 v[50:51], %[pz], s[52:53] op_sel_hi:[1,0]\n\t"                                                         \
+    "v_rcp_f32 v49, v49\n\t"                                                                                             \
+    "v_pk_mul_f32 v[52:53], %[pz], s[52:53] op_sel:[0,1] op_sel_hi:[1,1]\n\t"                                            \
+    "v_pk_fma_f32 v[50:51], %[py], s[50:51], v[50:51] op_sel_hi:[1,0,1]\n\t"                                             \
+    "v_pk_fma_f32 v[52:53], %[py], s[50:51], v[52:53] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                              \
+    "v_pk_fma_f32 v[50:51], %[px], s[48:49], v[50:51] op_sel_hi:[1,0,1]\n\t"                                             \
+    "v_pk_fma_f32 v[52:53], %[px], s[48:49], v[52:53] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                              \
+    "v_add_f32 v48, s59, v48\n\t"                                                                                        \
+    "v_mul_f32_e64 v54, -v48, v49\n\t"                                                                                   \
+    "v_cmp_le_f32 vcc, %[tmin], v54\n\t"                                                                                 \
+    "s_cbranch_vccz 10f\n\t"                                                                                             \
+    "v_fma_f32 v55, v54, v51, v50\n\t"                                                                                   \
+    "v_fma_f32 v56, v54, v53, v52\n\t"                                                                                   \
+    "v_add_f32 v55, s54, v55\n\t"                                                                                        \
+    "v_add_f32 v56, s55, v56\n\t"                                                                                        \
+    "v_cmp_le_f32_e64 s[52:53], v54, %[t]\n\t"                                                                           \
+    "v_cmp_le_f32_e64 s[48:49], 0, v56\n\t"                                                                              \
+    "v_cmp_le_f32_e64 s[50:51], 0, v55\n\t"                                                                              \
+    "s_and_b64 vcc, vcc, s[52:53]\n\t"                                                                                   \
+    "s_and_b64 s[48:49], s[48:49], s[50:51]\n\t"                                                                         \
+    "s_and_b64 vcc, vcc, s[48:49]\n\t"                                                                                   \
+    "s_cbranch_vccz 10f\n\t"                                                                                             \
+    "v_sub_f32 v56, 1.0, v56\n\t"                                                                                        \
+    "v_cmp_ne_u32_e64 s[48:49], s60, %[own]\n\t"                                                                         \
+    "v_cmp_le_f32_e64 s[50:51], v55, v56\n\t"                                                                            \
+    "s_and_b64 vcc, vcc, s[48:49]\n\t"                                                                                   \
+    "s_and_b64 vcc, vcc, s[50:51]\n\t"                                                                                   \
+    "s_and_saveexec_b64 s[48:49], vcc\n\t"                                                                               \
+    TAKE_T                                                                                                               \
+    "v_mov_b32 %[shape], %[cs]\n\t"                                                                                      \
+    "v_mov_b32 %[tri], s60\n\t"                                                                                          \
+    "s_mov_b64 exec, s[48:49]\n"                                                                                         \
+    "10:\n\t"                                                                                                            \
+    "s_add_i32 s62, s62, 48\n\t"                                                                                         \
+    "s_add_i32 s60, s60, 1\n\t"                                                                                          \
+    "s_sub_i32 s61, s61, 1\n\t"                                                                                          \
+    "s_cmp_lg_u32 s61, 0\n\t"                                                                                            \
+    "s_cbranch_scc1 8b\n\t"                                                                                              \
+    LEAF_END                                                                                                             \
+    "s_branch 4b\n"                                                                                                      \
+    "11:\n\t"                                                                                                            \
+    "s_brev_b32 %[cur], 1\n" /* RT_REF_NONE */                                                                           \
+    "9:\n\t"                                                                                                             \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define RT_BLAS_ASM(...) RT_BLAS_ASM_(__VA_ARGS__)
+// closest hit: the new bound is the hit's t, and the walk goes on; any hit: the lane is done (bound -inf),
+// and so is the wave once no lane has a bound above -inf
+#define RT_BLAS_TAKE_CLOSEST "v_mov_b32 %[t], v54\n\t"
+#define RT_BLAS_TAKE_ANY "v_mov_b32 %[t], 0xff800000\n\t"
+#define RT_BLAS_LEAF_END_CLOSEST ""
+#define RT_BLAS_LEAF_END_ANY              \
+    "v_cmp_lt_f32 vcc, 0xff800000, %[t]\n\t" \
+    "s_cbranch_vccz 11f\n\t"
+#define RT_BLAS_RUN(TEXT)                                                                                                   \
+    asm volatile(TEXT                                                                                                       \
+                 : [cur] "+s"(cur), [sp] "+s"(sp), [high] "+s"(high), [tos] "+v"(tos), [t] "+v"(s.t), [shape] "+v"(s.shape), \
+                   [tri] "+v"(s.tri)                                                                                        \
+                 : [nb] "s"(node_base), [tb] "s"(tri_base), [base] "s"(lds_base), [ixy] "v"(s.ixy), [nxy] "v"(s.nxy),       \
+                   [zin] "v"(s.zin), [px] "v"(s.px), [py] "v"(s.py), [pz] "v"(s.pz), [tmin] "s"(tmin_u), [own] "v"(own_tri), \
+                   [cs] "s"(cur_shape)                                                                                      \
+                 : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", \
+                   "s63", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", \
+                   "vcc", "scc", "memory")
+
+template <int OCT, bool ANYHIT>
+__device__ __forceinline__ int32_t packet_blas_asm(const RtSceneView &S, FastTrav &s, float tmin, WaveStack &stk, int32_t cur,
+                                                   int32_t cur_shape, int32_t own_tri) {
+    const void *node_base = S.nodes;
+    const void *tri_base = S.tri_xf;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)stk.base;
+    const float tmin_u = rt_as_float(__builtin_amdgcn_readfirstlane(rt_as_int(tmin)));
+    int32_t sp = __builtin_amdgcn_readfirstlane(stk.sp), high = __builtin_amdgcn_readfirstlane(stk.high), tos = stk.tos;
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    cur_shape = __builtin_amdgcn_readfirstlane(cur_shape);
+#define RT_BLAS_CASE(N, X, Y, Z)                                                                                   \
+    if constexpr (OCT == N) {                                                                                      \
+        if constexpr (ANYHIT && !RT_ANYHIT_ORDERED)                                                                \
+            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_WALK_LEFT_FIRST, RT_BLAS_TAKE_ANY, RT_BLAS_LEAF_END_ANY));         \
+        else if constexpr (ANYHIT)                                                                                 \
+            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_WALK_ORDERED(#N), RT_BLAS_TAKE_ANY, RT_BLAS_LEAF_END_ANY));        \
+        else                                                                                                       \
+            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_WALK_ORDERED(#N), RT_BLAS_TAKE_CLOSEST, RT_BLAS_LEAF_END_CLOSEST)); \
+    }
+    RT_BLAS_CASE(0, RT_WALK_X_POS, RT_WALK_Y_POS, RT_WALK_Z_POS)
+    RT_BLAS_CASE(1, RT_WALK_X_NEG, RT_WALK_Y_POS, RT_WALK_Z_POS)
+    RT_BLAS_CASE(2, RT_WALK_X_POS, RT_WALK_Y_NEG, RT_WALK_Z_POS)
+    RT_BLAS_CASE(3, RT_WALK_X_NEG, RT_WALK_Y_NEG, RT_WALK_Z_POS)
+    RT_BLAS_CASE(4, RT_WALK_X_POS, RT_WALK_Y_POS, RT_WALK_Z_NEG)
+    RT_BLAS_CASE(5, RT_WALK_X_NEG, RT_WALK_Y_POS, RT_WALK_Z_NEG)
+    RT_BLAS_CASE(6, RT_WALK_X_POS, RT_WALK_Y_NEG, RT_WALK_Z_NEG)
+    RT_BLAS_CASE(7, RT_WALK_X_NEG, RT_WALK_Y_NEG, RT_WALK_Z_NEG)
+#undef RT_BLAS_CASE
+    // The optimiser merges the eight callers' copies of this block's result tuple into one value, and a
+    // tuple with per-lane members counts as per-lane throughout: without these the walk's position, stack
+    // pointer and everything derived from them would move to vector registers and exec-mask branches.
+    stk.sp = __builtin_amdgcn_readfirstlane(sp);
+    stk.high = __builtin_amdgcn_readfirstlane(high);
+    stk.tos = tos;
+    return __builtin_amdgcn_readfirstlane(cur);
+}
+#endif
+
 // Traverses the scene with the wave's 64 * R rays (R per lane).  On entry s[r] holds the lane's
 // r-th world-space ray, search bound s[r].t (-inf for a slot without a ray), s[r].shape / .tri =
 // initial hit, and the origin primitive.  `lds_rows`: max_sp + 1 dwords for the stack, followed
@@ -368,6 +549,24 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
     int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
     bool in_instance = false;
     for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
+        if constexpr (R == 1) {
+            if (cur_shape >= 0 && dir_bits < 8u) {
+                // inside a mesh, all rays in one direction octant: the whole tree in one block of assembly
+                const int32_t own = cur_shape == s[0].org_shape ? s[0].org_tri : -1;
+                switch (dir_bits) {
+                case 0: cur = packet_blas_asm<0, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                case 1: cur = packet_blas_asm<1, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                case 2: cur = packet_blas_asm<2, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                case 3: cur = packet_blas_asm<3, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                case 4: cur = packet_blas_asm<4, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                case 5: cur = packet_blas_asm<5, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                case 6: cur = packet_blas_asm<6, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                default: cur = packet_blas_asm<7, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
+                }
+            }
+        }
+#endif
         if (cur >= 0) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
 #define RT_PACKET_WALK(N) \
