@@ -521,194 +521,158 @@ __device__ __forceinline__ int32_t packet_blas_asm(const RtSceneView &S, FastTra
 }
 #endif
 
-// Traverses the scene with the wave's 64 * R rays (R per lane).  On entry s[r] holds the lane's
-// r-th world-space ray, search bound s[r].t (-inf for a slot without a ray), s[r].shape / .tri =
-// initial hit, and the origin primitive.  `lds_rows`: max_sp + 1 dwords for the stack, followed
-// by 6 * R * 64 floats in which the world-space rays wait while the wave is inside an instance.
-// Returns false on stack overflow.
+// Traverses the scene with the wave's 64 rays (R = 1: one per lane; more per lane was measured and
+// dropped).  On entry s[0] holds the lane's world-space ray, search bound s[0].t (-inf for a slot
+// without a ray), s[0].shape / .tri = initial hit, and the origin primitive.  `lds_rows`: max_sp + 1
+// dwords for the stack, followed by 6 * 64 floats in which the world-space ray waits while the wave is
+// inside a mesh.  Returns false on stack overflow.
 //
-// R = 2 halves the number of steps per ray: the scalar work of a step (record fetch, ballots,
-// branches, stack) and the wait for the record are paid once for 128 rays, and the two
-// independent box / triangle tests of a lane interleave in the vector pipeline.
+// Two levels, two ray variables.  The outer loop walks the scene-level tree with the world ray and
+// never changes it.  A mesh (or instanced mesh) found in a scene-level leaf is traversed then and
+// there, start to finish, with a ray of its own in the mesh's space -- packet_blas_asm when all rays
+// share a direction octant -- and only the hit (bound, shape, triangle) comes back.  The world ray is
+// not kept in registers meanwhile: it is fetched again from LDS afterwards, so a mesh's tree runs with
+// one ray's worth of registers.  (An earlier form transformed the ray in place on the way into an
+// instance and restored it on the way out, inside one loop over both levels; the compiler then held the
+// ray twice and moved it from one set of registers to the other and back around every leaf.)
 template <bool ANYHIT, int R>
 __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (&s)[R], float tmin, int32_t *lds_rows, int max_sp) {
+    static_assert(R == 1, "one ray per lane");
+    constexpr bool ORDERED = !ANYHIT || RT_ANYHIT_ORDERED;
     const float ninf = -__builtin_inff();
-    float *world = reinterpret_cast<float *>(lds_rows + max_sp + 1) + (threadIdx.x & 63u);  // [6 * R][64]
-    bool live[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        live[r] = s[r].t > ninf;
-        world[(r * 6 + 0) * 64] = s[r].px.x; world[(r * 6 + 1) * 64] = s[r].py.x; world[(r * 6 + 2) * 64] = s[r].pz.x;
-        world[(r * 6 + 3) * 64] = s[r].px.y; world[(r * 6 + 4) * 64] = s[r].py.y; world[(r * 6 + 5) * 64] = s[r].pz.y;
-    }
-    const uint32_t world_bits = packet_direction_bits<R>(s, live);
-    uint32_t dir_bits = world_bits;
+    float *world = reinterpret_cast<float *>(lds_rows + max_sp + 1) + (threadIdx.x & 63u);  // [6][64]
+    bool live[1] = {s[0].t > ninf};
+    world[0 * 64] = s[0].px.x; world[1 * 64] = s[0].py.x; world[2 * 64] = s[0].pz.x;
+    world[3 * 64] = s[0].px.y; world[4 * 64] = s[0].py.y; world[5 * 64] = s[0].pz.y;
+    const uint32_t world_bits = packet_direction_bits<1>(s, live);
     WaveStack stk;
     stk.init(lds_rows);
     int32_t cur = S.tlas_root;
-    int32_t cur_shape = -1;  // >= 0 while inside the tree of a mesh / instanced mesh
-    bool in_instance = false;
     for (;;) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
-        if constexpr (R == 1) {
-            if (cur_shape >= 0 && dir_bits < 8u) {
-                // inside a mesh, all rays in one direction octant: the whole tree in one block of assembly
-                const int32_t own = cur_shape == s[0].org_shape ? s[0].org_tri : -1;
-                switch (dir_bits) {
-                case 0: cur = packet_blas_asm<0, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                case 1: cur = packet_blas_asm<1, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                case 2: cur = packet_blas_asm<2, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                case 3: cur = packet_blas_asm<3, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                case 4: cur = packet_blas_asm<4, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                case 5: cur = packet_blas_asm<5, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                case 6: cur = packet_blas_asm<6, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                default: cur = packet_blas_asm<7, ANYHIT>(S, s[0], tmin, stk, cur, cur_shape, own); break;
-                }
-            }
-        }
-#endif
         if (cur >= 0) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
-#define RT_PACKET_WALK(N) \
-    (R == 1 ? packet_walk_asm<N, !ANYHIT || RT_ANYHIT_ORDERED>(S, s[0], tmin, stk, cur) \
-            : packet_walk<N, R, !ANYHIT || RT_ANYHIT_ORDERED>(S, s, tmin, stk, cur, dir_bits))
-#else
-#define RT_PACKET_WALK(N) packet_walk<N, R, !ANYHIT || RT_ANYHIT_ORDERED>(S, s, tmin, stk, cur, dir_bits)
-#endif
-            switch (dir_bits) {
-            case 0: cur = RT_PACKET_WALK(0); break;
-            case 1: cur = RT_PACKET_WALK(1); break;
-            case 2: cur = RT_PACKET_WALK(2); break;
-            case 3: cur = RT_PACKET_WALK(3); break;
-            case 4: cur = RT_PACKET_WALK(4); break;
-            case 5: cur = RT_PACKET_WALK(5); break;
-            case 6: cur = RT_PACKET_WALK(6); break;
-            case 7: cur = RT_PACKET_WALK(7); break;
-            default: cur = packet_walk<8, R, !ANYHIT || RT_ANYHIT_ORDERED>(S, s, tmin, stk, cur, dir_bits); break;
+            switch (world_bits) {
+            case 0: cur = packet_walk_asm<0, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 1: cur = packet_walk_asm<1, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 2: cur = packet_walk_asm<2, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 3: cur = packet_walk_asm<3, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 4: cur = packet_walk_asm<4, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 5: cur = packet_walk_asm<5, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 6: cur = packet_walk_asm<6, ORDERED>(S, s[0], tmin, stk, cur); break;
+            case 7: cur = packet_walk_asm<7, ORDERED>(S, s[0], tmin, stk, cur); break;
+            default: cur = packet_walk<8, 1, ORDERED>(S, s, tmin, stk, cur, world_bits); break;
             }
+#else
+            cur = packet_walk<8, 1, ORDERED>(S, s, tmin, stk, cur, world_bits);
+#endif
         }
         if (cur == RT_REF_NONE) break;
-        if (cur == RT_REF_EXIT_BLAS) {
-            if (in_instance) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    fast_set_ray(s[r], world[(r * 6 + 0) * 64], world[(r * 6 + 1) * 64], world[(r * 6 + 2) * 64],
-                                 world[(r * 6 + 3) * 64], world[(r * 6 + 4) * 64], world[(r * 6 + 5) * 64]);
-                dir_bits = world_bits;
-                in_instance = false;
-            }
-            cur_shape = -1;
-            cur = stk.pop();
-            continue;
-        }
+        // a scene-level leaf
         const uint32_t v = (uint32_t)~cur;
         const uint32_t cnt = v & 7u, first = v >> 3;
-        if (cur_shape >= 0) {
-            // the triangle a lane's ray starts on, if it belongs to this mesh (it is skipped)
-            int32_t own_tri[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) own_tri[r] = cur_shape == s[r].org_shape ? s[r].org_tri : -1;
-            const char *tri_base = reinterpret_cast<const char *>(S.tri_xf);
-            uint32_t at = first * (uint32_t)sizeof(RtTriXf);
-            for (uint32_t k = 0; k < cnt; ++k, at += (uint32_t)sizeof(RtTriXf)) {
-                const int32_t gtri = (int32_t)(first + k);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
-                if constexpr (R == 1) {
-                    float t, beta, gamma;
-                    packet_triangle_asm(tri_base, at, s[0], t, beta, gamma);
-                    const bool hit = t >= tmin && t <= s[0].t && gamma >= 0.0f && beta >= 0.0f && beta <= 1.0f - gamma;
-                    if (hit && gtri != own_tri[0]) {
-                        s[0].shape = cur_shape;
-                        s[0].tri = gtri;
-                        s[0].t = ANYHIT ? ninf : t;
-                    }
-                    continue;
-                }
-#endif
-                rt_f4 uv0, uv1, tn;
-                rt_fetch_48(tri_base, at, uv0, uv1, tn);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float t;
-                    if (fast_triangle(s[r], uv0, uv1, tn, tmin, t) && gtri != own_tri[r]) {
-                        s[r].shape = cur_shape;
-                        s[r].tri = gtri;
-                        s[r].t = ANYHIT ? ninf : t;
-                    }
-                }
-            }
-            bool any_left = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) any_left = any_left || s[r].t > ninf;
-            cur = (ANYHIT && __ballot(any_left) == 0ull) ? RT_REF_NONE : stk.pop();
-            continue;
-        }
-        bool entered = false;
-        for (uint32_t k = 0; k < cnt && !entered; ++k) {
+        bool done = false;
+        for (uint32_t k = 0; k < cnt && !done; ++k) {
             rt_f4 h, pp1, pp2, pp3;  // the whole RtTPrim
             rt_fetch_node(S.tprims, (first + k) * (uint32_t)sizeof(RtTPrim), h, pp1, pp2, pp3);
-            const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z),
-                          proto_type = rt_as_int(h.w);
+            const int32_t type = rt_as_int(h.x), shape_id = rt_as_int(h.y), blas_root = rt_as_int(h.z), proto_type = rt_as_int(h.w);
             const bool is_inst = type == RT_SHAPE_INSTANCE;
             if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
                 if (is_inst) {
                     // enter the instance only if some ray of the wave reaches its world box
-                    const rt_f4 f0 = pp1, f1 = pp2;
-                    bool reach = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float e;
-                        reach = reach || fast_box(s[r], f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, tmin, e);
-                    }
-                    if (__ballot(reach) == 0ull) continue;
+                    float e;
+                    if (__ballot(fast_box(s[0], pp1.x, pp1.y, pp1.z, pp1.w, pp2.x, pp2.y, tmin, e)) == 0ull) continue;
                 }
-                if (k + 1 < cnt) stk.push(rt_make_leaf_ref(first + k + 1, cnt - k - 1));
-                stk.push(RT_REF_EXIT_BLAS);
+                // the ray in the mesh's space, with the hit so far
+                FastTrav m[1];
+                uint32_t bits = world_bits;
                 if (is_inst) {
                     rt_f4 r0, r1, r2;
                     rt_fetch_48(S.tprim_xf, (first + k) * 48u, r0, r1, r2);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float wox = s[r].px.x, woy = s[r].py.x, woz = s[r].pz.x, wdx = s[r].px.y, wdy = s[r].py.y, wdz = s[r].pz.y;
-                        fast_set_ray(s[r], ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
-                                     ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
-                                     ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
-                                     (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
-                                     (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
-                    }
-                    dir_bits = packet_direction_bits<R>(s, live);
-                    in_instance = true;
+                    const float wox = s[0].px.x, woy = s[0].py.x, woz = s[0].pz.x, wdx = s[0].px.y, wdy = s[0].py.y, wdz = s[0].pz.y;
+                    fast_set_ray(m[0], ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w, ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
+                                 ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w, (r0.x * wdx + r0.y * wdy) + r0.z * wdz,
+                                 (r1.x * wdx + r1.y * wdy) + r1.z * wdz, (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+                    bits = packet_direction_bits<1>(m, live);
+                } else {
+                    m[0].px = s[0].px; m[0].py = s[0].py; m[0].pz = s[0].pz;
+                    m[0].ixy = s[0].ixy; m[0].nxy = s[0].nxy; m[0].zin = s[0].zin;
                 }
-                cur_shape = shape_id;
-                cur = blas_root;
-                entered = true;
+                m[0].t = s[0].t;
+                m[0].shape = s[0].shape;
+                m[0].tri = s[0].tri;
+                const int32_t own = shape_id == s[0].org_shape ? s[0].org_tri : -1;
+                stk.push(RT_REF_EXIT_BLAS);
+                int32_t c = blas_root;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
+                if (bits < 8u) {
+                    switch (bits) {
+                    case 0: c = packet_blas_asm<0, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    case 1: c = packet_blas_asm<1, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    case 2: c = packet_blas_asm<2, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    case 3: c = packet_blas_asm<3, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    case 4: c = packet_blas_asm<4, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    case 5: c = packet_blas_asm<5, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    case 6: c = packet_blas_asm<6, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    default: c = packet_blas_asm<7, ANYHIT>(S, m[0], tmin, stk, c, shape_id, own); break;
+                    }
+                } else
+#endif
+                {
+                    // rays of mixed direction signs: the general node test, triangles one at a time
+                    const char *tri_base = reinterpret_cast<const char *>(S.tri_xf);
+                    for (;;) {
+                        if (c >= 0) c = packet_walk<8, 1, ORDERED>(S, m, tmin, stk, c, bits);
+                        if (c == RT_REF_NONE || c == RT_REF_EXIT_BLAS) break;
+                        const uint32_t lv = (uint32_t)~c;
+                        const uint32_t lcnt = lv & 7u, lfirst = lv >> 3;
+                        uint32_t at = lfirst * (uint32_t)sizeof(RtTriXf);
+                        for (uint32_t j = 0; j < lcnt; ++j, at += (uint32_t)sizeof(RtTriXf)) {
+                            const int32_t gtri = (int32_t)(lfirst + j);
+                            float t;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PACKET_WALK_IN_CXX)
+                            float beta, gamma;
+                            packet_triangle_asm(tri_base, at, m[0], t, beta, gamma);
+                            const bool tri_hit = t >= tmin && t <= m[0].t && gamma >= 0.0f && beta >= 0.0f && beta <= 1.0f - gamma;
+#else
+                            rt_f4 uv0, uv1, tn;
+                            rt_fetch_48(tri_base, at, uv0, uv1, tn);
+                            const bool tri_hit = fast_triangle(m[0], uv0, uv1, tn, tmin, t);
+#endif
+                            if (tri_hit && gtri != own) {
+                                m[0].shape = shape_id;
+                                m[0].tri = gtri;
+                                m[0].t = ANYHIT ? ninf : t;
+                            }
+                        }
+                        c = (ANYHIT && __ballot(m[0].t > ninf) == 0ull) ? RT_REF_NONE : stk.pop();
+                    }
+                }
+                s[0].t = m[0].t;
+                s[0].shape = m[0].shape;
+                s[0].tri = m[0].tri;
+                done = c == RT_REF_NONE;  // an any-hit wave with no lane left looking
+                // the world ray again, for the rest of this leaf and the walk after it
+                fast_set_ray(s[0], world[0 * 64], world[1 * 64], world[2 * 64], world[3 * 64], world[4 * 64], world[5 * 64]);
             } else {
-                // sphere / box / triangle at scene level, possibly instanced (s holds the world rays here)
-                const rt_f4 f0 = pp1, f1 = pp2, f2 = pp3;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float t;
-                    bool hit;
-                    if (is_inst) {
-                        FastTrav lr;
-                        fast_local_ray(S, first + k, true, s[r].px.x, s[r].py.x, s[r].pz.x, s[r].px.y, s[r].py.y, s[r].pz.y, s[r], lr);
-                        hit = fast_payload_hit(lr, proto_type, f0, f1, f2, tmin, t);
-                    } else {
-                        hit = fast_payload_hit(s[r], type, f0, f1, f2, tmin, t);
-                    }
-                    if (hit && shape_id != s[r].org_shape) {
-                        s[r].shape = shape_id;
-                        s[r].tri = -1;
-                        s[r].t = ANYHIT ? ninf : t;
-                    }
+                // sphere / box / triangle at scene level, possibly instanced
+                float t;
+                bool hit;
+                if (is_inst) {
+                    FastTrav lr;
+                    fast_local_ray(S, first + k, true, s[0].px.x, s[0].py.x, s[0].pz.x, s[0].px.y, s[0].py.y, s[0].pz.y, s[0], lr);
+                    hit = fast_payload_hit(lr, proto_type, pp1, pp2, pp3, tmin, t);
+                } else {
+                    hit = fast_payload_hit(s[0], type, pp1, pp2, pp3, tmin, t);
+                }
+                if (hit && shape_id != s[0].org_shape) {
+                    s[0].shape = shape_id;
+                    s[0].tri = -1;
+                    s[0].t = ANYHIT ? ninf : t;
                 }
             }
         }
-        if (entered) continue;
-        bool any_left = false;
-#pragma unroll
-        for (int r = 0; r < R; ++r) any_left = any_left || s[r].t > ninf;
-        cur = (ANYHIT && __ballot(any_left) == 0ull) ? RT_REF_NONE : stk.pop();
+        if (done) break;
+        cur = (ANYHIT && __ballot(s[0].t > ninf) == 0ull) ? RT_REF_NONE : stk.pop();
     }
     // The host sizes the rows for the deepest path, so this cannot fail; if it ever did, the surplus
     // entries have overwritten the world rays stored behind the rows and the frame is reported as failed.
