@@ -30,19 +30,18 @@
 // Register budgets (waves per SIMD the compiler must make room for; 512 VGPRs / waves).  These
 // kernels wait on memory most of the time, so one more resident wave is worth more than the
 // handful of values that get spilled for it -- as long as the spills stay out of the loops:
-//   packets   8 waves (64 VGPRs, 36..48 B of scratch in the scene-level primitive code): bunny frame
-//             camera rays 0.326 -> 0.312 ms, shadow rays 0.794 -> 0.736 ms; 7 waves lies in between
+//   packets   8 waves (64 VGPRs, no scratch since a mesh is walked with a ray variable of its own)
 //   shade     behind camera rays (k_shade<true>, no loop, no queue code): 6 waves (79 VGPRs, 12 B of scratch),
 //             bunny frame 0.318 -> 0.253 ms (5 waves: 0.267); behind mirror bounces (k_shade<false>): 6 waves
 //             too (78 VGPRs, no scratch) since it covers the queue with its grid instead of striding over it
 //             in a loop, which alone took 125 registers (cornell_room: 0.555 -> 0.538 ms over its six launches)
-//   shadow rays + light sums in one kernel: 7 waves (72 VGPRs); at 8 it spills 24 B and the frame is 5 %
-//             slower, at 7 it is as fast as separate kernels (bunny, 2 lights) or 7 % faster (spheres_1K,
-//             4 lights)
+//   shadow rays + light sums in one kernel: 8 waves (64 VGPRs, no scratch): bunny frame 0.862 -> 0.847 ms,
+//             spheres_1K 0.594 -> 0.585, cornell_room 0.914 -> 0.903 over 7 waves.  (While the walk still
+//             transformed the ray in place at an instance the kernel needed 72 registers and lost 5 % at 8 waves.)
 //   accumulate 8 waves (60 VGPRs, no scratch; 76 without the hint): 0.195 -> 0.183 ms
 #define RT_PACKET_WAVES 8
 #ifndef RT_FUSED_WAVES
-#define RT_FUSED_WAVES 7
+#define RT_FUSED_WAVES 8
 #endif
 #define RT_SHADE_WAVES 6
 #ifndef RT_SHADE_FIRST_WAVES
