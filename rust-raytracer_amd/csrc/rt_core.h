@@ -980,15 +980,36 @@ struct ColorF {
     float r, g, b;
 };
 
+// 1/sqrt(x) and x^p (x >= 0) for the fast mode's light sums: the hardware's reciprocal square root and
+// base-2 logarithm / exponential (one unit in the last place each), where the correctly rounded sqrt,
+// division and powf cost 20, 20 and over 100 instructions.  x^p = 2^(p log2 x) is then off by about
+// |p log2 x| * 1e-7, relatively: 1e-6 for a highlight that is still visible, in a colour that is quantised
+// to 1 / 255.  x = 0 gives 2^-inf = 0; p = 0 gives 1 for x > 0 and, by the explicit test, for x = 0 as powf does.
+RT_HD float rt_rsqrt_approx(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / __builtin_sqrtf(x);
+#endif
+}
+RT_HD float rt_pow_approx(float x, float p) {
+    if (p == 0.0f) return 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));
+#else
+    return __builtin_exp2f(p * __builtin_log2f(x));
+#endif
+}
+
 // One light's contribution (lambertian.rs:29-34, blinn_phong.rs:35-45).
 // `stl` is the un-normalised surface-to-light vector the light returned.
 //
 // F32 = false: the reference's arithmetic (f64 normalisations and dot products, the cosine rounded to
 // f32 where the reference rounds it).  F32 = true (fast mode): the same formulas on the f32-rounded
-// vectors, with cos = (n . l) / |l| in place of n . (l / |l|).  Hit point, normal and directions are still
-// the f64 ones; only these few products change, by parts in 1e7 of a colour that is quantised to 8 bits
-// (measured on the 1000 x 1000 frames: PSNR against the f64 oracle unchanged to three digits, bunny 71.07
-// dB either way), and the light sums of a frame take a third less time.
+// vectors, with cos = (n . l) / |l| in place of n . (l / |l|), 1 / |.| from rt_rsqrt_approx and the
+// highlight's power from rt_pow_approx.  Hit point, normal and directions are still the f64 ones; only
+// these few products change, by parts in 1e6 of a colour that is quantised to 8 bits (measured on the
+// 1000 x 1000 frames: PSNR against the f64 oracle unchanged to three digits).
 template <bool F32>
 RT_HD void add_light(const RtShader &sh, const RtLight &light, const D3 &normal, const D3 &stl, const D3 &ray_dir,
                      ColorF &color) {
@@ -996,14 +1017,14 @@ RT_HD void add_light(const RtShader &sh, const RtLight &light, const D3 &normal,
     if (F32) {
         const float nx = (float)normal.x, ny = (float)normal.y, nz = (float)normal.z;
         const float lx = (float)stl.x, ly = (float)stl.y, lz = (float)stl.z;
-        const float inv_l = 1.0f / __builtin_sqrtf(lx * lx + ly * ly + lz * lz);
+        const float inv_l = rt_rsqrt_approx(lx * lx + ly * ly + lz * lz);
         k = rt_fmax((nx * lx + ny * ly + nz * lz) * inv_l, 0.0f);
         if (sh.type == RT_SHADER_BLINN_PHONG) {
             const float dx = (float)ray_dir.x, dy = (float)ray_dir.y, dz = (float)ray_dir.z;
-            const float inv_d = 1.0f / __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const float inv_d = rt_rsqrt_approx(dx * dx + dy * dy + dz * dz);
             const float hx = lx * inv_l - dx * inv_d, hy = ly * inv_l - dy * inv_d, hz = lz * inv_l - dz * inv_d;
-            const float inv_h = 1.0f / __builtin_sqrtf(hx * hx + hy * hy + hz * hz);
-            s = __builtin_powf(rt_fmax((nx * hx + ny * hy + nz * hz) * inv_h, 0.0f), sh.shininess);
+            const float inv_h = rt_rsqrt_approx(hx * hx + hy * hy + hz * hz);
+            s = rt_pow_approx(rt_fmax((nx * hx + ny * hy + nz * hz) * inv_h, 0.0f), sh.shininess);
         }
     } else {
         const D3 stol_normal = normalize(stl);
