@@ -351,7 +351,10 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
 // Acceptance, cheapest first, each step skipped when no lane is left: t >= tmin; gamma >= 0, beta >= 0,
 // t <= bound; beta <= 1 - gamma and "not the triangle the ray starts on".  Lanes that pass take the hit
 // under an exec mask.  s60 = index of the triangle, s61 = triangles left in the leaf, s62 = byte offset
-// of its record; t, beta, gamma in v54..v56.
+// of its record; t, beta, gamma in v54..v56; s[64:69] hold the last two words of the record and the lane
+// masks of the tests.  Everything a test reads from the triangle's record is read in its first 14
+// instructions; the load of the leaf's next record into the same registers is issued right after them, so
+// that its latency passes behind the acceptance tests instead of in front of the next triangle.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_BLAS_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER, TAKE_T, LEAF_END)    \
     "s_cmp_lt_i32 %[cur], 0\n\t"                                                                                         \
@@ -410,10 +413,10 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
     "s_not_b32 s60, %[cur]\n\t"                                                                                          \
     "s_and_b32 s61, s60, 7\n\t"                                                                                          \
     "s_lshr_b32 s60, s60, 3\n\t"                                                                                         \
-    "s_mul_i32 s62, s60, 48\n"                                                                                           \
-    "8:\n\t"                                                                                                             \
+    "s_mul_i32 s62, s60, 48\n\t"                                                                                        \
     "s_load_dwordx8 s[48:55], %[tb], s62\n\t"                                                                            \
-    "s_load_dwordx4 s[56:59], %[tb], s62 offset:0x20\n\t"                                                                \
+    "s_load_dwordx4 s[56:59], %[tb], s62 offset:0x20\n"                                                                  \
+    "8:\n\t"                                                                                                             \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
     "s_nop 0\n\t"                                                                                                        \
     "v_pk_mul_f32 v[48:49], %[pz], s[58:59] op_sel_hi:[1,0]\n\t"                                                         \
@@ -428,33 +431,39 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
     "v_pk_fma_f32 v[52:53], %[px], s[48:49], v[52:53] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                              \
     "v_add_f32 v48, s59, v48\n\t"                                                                                        \
     "v_mul_f32_e64 v54, -v48, v49\n\t"                                                                                   \
+    "s_mov_b64 s[64:65], s[54:55]\n\t" /* the record is read: its registers take the leaf's next one meanwhile */       \
+    "s_add_i32 s62, s62, 48\n\t"                                                                                         \
+    "s_sub_i32 s61, s61, 1\n\t"                                                                                          \
+    "s_cmp_lg_u32 s61, 0\n\t"                                                                                            \
+    "s_cbranch_scc0 12f\n\t"                                                                                             \
+    "s_load_dwordx8 s[48:55], %[tb], s62\n\t"                                                                            \
+    "s_load_dwordx4 s[56:59], %[tb], s62 offset:0x20\n"                                                                  \
+    "12:\n\t"                                                                                                            \
     "v_cmp_le_f32 vcc, %[tmin], v54\n\t"                                                                                 \
     "s_cbranch_vccz 10f\n\t"                                                                                             \
     "v_fma_f32 v55, v54, v51, v50\n\t"                                                                                   \
     "v_fma_f32 v56, v54, v53, v52\n\t"                                                                                   \
-    "v_add_f32 v55, s54, v55\n\t"                                                                                        \
-    "v_add_f32 v56, s55, v56\n\t"                                                                                        \
-    "v_cmp_le_f32_e64 s[52:53], v54, %[t]\n\t"                                                                           \
-    "v_cmp_le_f32_e64 s[48:49], 0, v56\n\t"                                                                              \
-    "v_cmp_le_f32_e64 s[50:51], 0, v55\n\t"                                                                              \
-    "s_and_b64 vcc, vcc, s[52:53]\n\t"                                                                                   \
-    "s_and_b64 s[48:49], s[48:49], s[50:51]\n\t"                                                                         \
-    "s_and_b64 vcc, vcc, s[48:49]\n\t"                                                                                   \
+    "v_add_f32 v55, s64, v55\n\t"                                                                                        \
+    "v_add_f32 v56, s65, v56\n\t"                                                                                        \
+    "v_cmp_le_f32_e64 s[68:69], v54, %[t]\n\t"                                                                           \
+    "v_cmp_le_f32_e64 s[64:65], 0, v56\n\t"                                                                              \
+    "v_cmp_le_f32_e64 s[66:67], 0, v55\n\t"                                                                              \
+    "s_and_b64 vcc, vcc, s[68:69]\n\t"                                                                                   \
+    "s_and_b64 s[64:65], s[64:65], s[66:67]\n\t"                                                                         \
+    "s_and_b64 vcc, vcc, s[64:65]\n\t"                                                                                   \
     "s_cbranch_vccz 10f\n\t"                                                                                             \
     "v_sub_f32 v56, 1.0, v56\n\t"                                                                                        \
-    "v_cmp_ne_u32_e64 s[48:49], s60, %[own]\n\t"                                                                         \
-    "v_cmp_le_f32_e64 s[50:51], v55, v56\n\t"                                                                            \
-    "s_and_b64 vcc, vcc, s[48:49]\n\t"                                                                                   \
-    "s_and_b64 vcc, vcc, s[50:51]\n\t"                                                                                   \
-    "s_and_saveexec_b64 s[48:49], vcc\n\t"                                                                               \
+    "v_cmp_ne_u32_e64 s[64:65], s60, %[own]\n\t"                                                                         \
+    "v_cmp_le_f32_e64 s[66:67], v55, v56\n\t"                                                                            \
+    "s_and_b64 vcc, vcc, s[64:65]\n\t"                                                                                   \
+    "s_and_b64 vcc, vcc, s[66:67]\n\t"                                                                                   \
+    "s_and_saveexec_b64 s[64:65], vcc\n\t"                                                                               \
     TAKE_T                                                                                                               \
     "v_mov_b32 %[shape], %[cs]\n\t"                                                                                      \
     "v_mov_b32 %[tri], s60\n\t"                                                                                          \
-    "s_mov_b64 exec, s[48:49]\n"                                                                                         \
+    "s_mov_b64 exec, s[64:65]\n"                                                                                         \
     "10:\n\t"                                                                                                            \
-    "s_add_i32 s62, s62, 48\n\t"                                                                                         \
     "s_add_i32 s60, s60, 1\n\t"                                                                                          \
-    "s_sub_i32 s61, s61, 1\n\t"                                                                                          \
     "s_cmp_lg_u32 s61, 0\n\t"                                                                                            \
     "s_cbranch_scc1 8b\n\t"                                                                                              \
     LEAF_END                                                                                                             \
@@ -480,8 +489,8 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
                    [zin] "v"(s.zin), [px] "v"(s.px), [py] "v"(s.py), [pz] "v"(s.pz), [tmin] "s"(tmin_u), [own] "v"(own_tri), \
                    [cs] "s"(cur_shape)                                                                                      \
                  : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", \
-                   "s63", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", \
-                   "vcc", "scc", "memory")
+                   "s63", "s64", "s65", "s66", "s67", "s68", "s69", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
+                   "v56", "v57", "v58", "v59", "v60", "v61", "vcc", "scc", "memory")
 
 template <int OCT, bool ANYHIT>
 __device__ __forceinline__ int32_t packet_blas_asm(const RtSceneView &S, FastTrav &s, float tmin, WaveStack &stk, int32_t cur,
