@@ -431,9 +431,74 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     accumulate_body(S, Q, B, ids, Q.lit_list[e]);
 }
 
+// The per-pixel sum of resolve_body, with the samples brought in through LDS.  A pixel's samples are
+// consecutive floats (27 of them at 9 rays per pixel), so a lane that reads its own pixel's samples
+// walks through memory with a stride of 108 bytes: every load instruction of the wave touches about a
+// hundred cache lines, and the kernel ran at the rate the vector memory unit looks lines up (2.2 TB/s)
+// instead of the rate HBM delivers them.  Here the wave loads the samples of its 64 pixels, which are
+// consecutive in memory, as consecutive floats (RT_RESOLVE_ROUND samples per pixel at a time), puts them
+// into a table in LDS whose row length is odd (no bank conflicts), and each lane then adds up its own
+// row in the same order as before: same sums, bit for bit.
+#define RT_RESOLVE_ROUND 9
+#define RT_RESOLVE_ROW (3 * RT_RESOLVE_ROUND)  // odd
 __global__ void __launch_bounds__(RT_BLOCK) k_resolve(RtBuffers Q, RtBatch B, float *fb) {
-    for (uint32_t lp = blockIdx.x * RT_BLOCK + threadIdx.x; lp < B.n_pixels; lp += gridDim.x * RT_BLOCK)
-        resolve_body(Q, B, lp, fb);
+    __shared__ float stage[RT_BLOCK / 64][64 * RT_RESOLVE_ROW];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float *st = stage[wave];
+    const uint32_t spp = B.n * B.n;
+    const uint32_t n_groups = (B.n_pixels + 63u) / 64u;
+    const float div = (float)(uint16_t)(B.n * B.n);
+    for (uint32_t g0 = blockIdx.x * (RT_BLOCK / 64); g0 < n_groups; g0 += gridDim.x * (RT_BLOCK / 64)) {  // the same trips for the whole block
+        const uint32_t group = g0 + wave;
+        const uint32_t lp = group * 64u + lane;
+        const bool mine = group < n_groups && lp < B.n_pixels;
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (uint32_t k0 = 0; k0 < spp; k0 += RT_RESOLVE_ROUND) {
+            const uint32_t per_px = 3u * min(spp - k0, (uint32_t)RT_RESOLVE_ROUND);  // floats per pixel in this round
+            // float f = lane + 64 m of the round belongs to pixel f / per_px of the group, element f % per_px
+            const uint32_t step_px = 64u / per_px, step_el = 64u % per_px;
+            uint32_t px = lane / per_px, el = lane - px * per_px;
+            const uint32_t last_px = B.n_pixels - 1u;  // a pixel past the end reads the last one's samples; nobody adds them up
+            if (per_px == RT_RESOLVE_ROW) {
+                // a full round: all loads first, then all stores, so that the loads are in flight together
+                float v[RT_RESOLVE_ROW];
+                uint32_t at[RT_RESOLVE_ROW];
+#pragma unroll
+                for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) {
+                    const uint32_t src_px = min(group * 64u + px, last_px);
+                    v[m] = RT_STREAM_LD(Q.color[((size_t)src_px * spp + k0) * 3 + el]);
+                    at[m] = px * RT_RESOLVE_ROW + el;
+                    px += 64u / RT_RESOLVE_ROW;
+                    el += 64u % RT_RESOLVE_ROW;
+                    if (el >= RT_RESOLVE_ROW) { el -= RT_RESOLVE_ROW; px += 1; }
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) st[at[m]] = v[m];
+            } else {
+                for (uint32_t m = 0; m < per_px; ++m) {
+                    const uint32_t src_px = min(group * 64u + px, last_px);
+                    st[px * RT_RESOLVE_ROW + el] = RT_STREAM_LD(Q.color[((size_t)src_px * spp + k0) * 3 + el]);
+                    px += step_px;
+                    el += step_el;
+                    if (el >= per_px) { el -= per_px; px += 1; }
+                }
+            }
+            __syncthreads();
+            if (mine)
+                for (uint32_t e = 0; e < per_px; e += 3) {  // p-major, q-minor: sample k = p*n + q
+                    r += st[lane * RT_RESOLVE_ROW + e + 0];
+                    g += st[lane * RT_RESOLVE_ROW + e + 1];
+                    b += st[lane * RT_RESOLVE_ROW + e + 2];
+                }
+            __syncthreads();
+        }
+        float *out;
+        if (mine && resolve_address(B, lp, fb, out)) {
+            out[0] = r / div;
+            out[1] = g / div;
+            out[2] = b / div;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_fill_i32(int32_t *p, size_t n, int32_t v) {

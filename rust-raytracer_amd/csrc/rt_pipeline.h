@@ -543,25 +543,31 @@ RT_HD bool accumulate_body(const RtSceneView &S, const RtBuffers &Q, const RtBat
 }
 
 // ---- resolve: render.rs:63-83, framebuffer.rs:21-31
-RT_HD void resolve_body(const RtBuffers &Q, const RtBatch &B, uint32_t lp, float *fb) {
+// Where pixel lp of the batch lies in the framebuffer (false: a padding pixel of a tile that sticks out).
+RT_HD bool resolve_address(const RtBatch &B, uint32_t lp, float *fb, float *&px) {
     uint32_t i, j;
-    if (!batch_pixel(B, lp, i, j)) return;
-    const uint32_t spp = B.n * B.n;
-    const float *c = Q.color + (size_t)lp * spp * 3;
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-    for (uint32_t k = 0; k < spp; ++k) {  // p-major, q-minor: k = p*n + q
-        r += c[k * 3 + 0];  // (plain loads: a thread walks through consecutive floats of the same lines)
-        g += c[k * 3 + 1];
-        b += c[k * 3 + 2];
-    }
-    const float div = (float)(uint16_t)(B.n * B.n);
-    float *px;
+    if (!batch_pixel(B, lp, i, j)) return false;
     if (B.compact_fb) {
         const uint32_t tp = B.tile_w * B.tile_h;  // tiles are stored row-major whatever the order they were worked in
         px = fb + ((size_t)(B.slot0 + rt_div(lp, B.div_tile_px)) * tp + (size_t)(j % B.tile_h) * B.tile_w + i % B.tile_w) * 3;
     } else {
         px = fb + ((size_t)i + (size_t)j * B.width) * 3;
     }
+    return true;
+}
+
+RT_HD void resolve_body(const RtBuffers &Q, const RtBatch &B, uint32_t lp, float *fb) {
+    float *px;
+    if (!resolve_address(B, lp, fb, px)) return;
+    const uint32_t spp = B.n * B.n;
+    const float *c = Q.color + (size_t)lp * spp * 3;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < spp; ++k) {  // p-major, q-minor: k = p*n + q
+        r += c[k * 3 + 0];
+        g += c[k * 3 + 1];
+        b += c[k * 3 + 2];
+    }
+    const float div = (float)(uint16_t)(B.n * B.n);
     px[0] = r / div;
     px[1] = g / div;
     px[2] = b / div;
