@@ -31,8 +31,10 @@
 // kernels wait on memory most of the time, so one more resident wave is worth more than the
 // handful of values that get spilled for it -- as long as the spills stay out of the loops:
 //   packets   8 waves (64 VGPRs, no scratch since a mesh is walked with a ray variable of its own)
-//   shade     behind camera rays (k_shade<true>, no loop, no queue code): 6 waves (79 VGPRs, 12 B of scratch),
-//             bunny frame 0.318 -> 0.253 ms (5 waves: 0.267); behind mirror bounces (k_shade<false>): 6 waves
+//   shade     behind camera rays (k_shade<true>, no loop, no queue code): 7 waves (72 VGPRs, 100 B of scratch in
+//             the box and sphere branches), bunny frame 0.192 -> 0.180 ms and cornell_room 0.512 -> 0.505 over 6
+//             waves (79 VGPRs, 12 B); at 8 waves the spills reach the triangle path and it takes twice as long;
+//             behind mirror bounces (k_shade<false>): 6 waves
 //             too (78 VGPRs, no scratch) since it covers the queue with its grid instead of striding over it
 //             in a loop, which alone took 125 registers (cornell_room: 0.555 -> 0.538 ms over its six launches)
 //   shadow rays + light sums in one kernel: 8 waves (64 VGPRs, no scratch): bunny frame 0.862 -> 0.847 ms,
@@ -45,7 +47,7 @@
 #endif
 #define RT_SHADE_WAVES 6
 #ifndef RT_SHADE_FIRST_WAVES
-#define RT_SHADE_FIRST_WAVES 6
+#define RT_SHADE_FIRST_WAVES 7
 #endif
 #define RT_ACC_WAVES 8
 
