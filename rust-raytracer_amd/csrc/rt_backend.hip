@@ -45,7 +45,9 @@
 #ifndef RT_FUSED_WAVES
 #define RT_FUSED_WAVES 8
 #endif
+#ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 6
+#endif
 #ifndef RT_SHADE_FIRST_WAVES
 #define RT_SHADE_FIRST_WAVES 7
 #endif
