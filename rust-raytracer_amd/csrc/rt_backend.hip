@@ -269,37 +269,73 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
     return v;
 }
 
+// The kernel's arguments as they lie in its argument segment (by-value arguments follow one another
+// at their natural alignment, like the members of a struct).  The compiler loads every argument field a
+// kernel uses into scalar registers at the top and keeps it there; this kernel uses some forty pointers
+// but has fifty-odd scalar registers besides the walk's, so most of them were parked in lanes of a vector
+// register and read back, one vector instruction per register, once per light and again after the walk
+// (an eighth of the kernel's vector instructions).  Fields that the walk itself does not need are
+// therefore read where they are used, through a pointer to the argument segment that the compiler
+// cannot see through (`fresh`): scalar loads that hit the scalar cache, and no long-lived registers.
+struct FusedKernargs {
+    RtSceneView S;
+    RtBuffers Q;
+    RtBatch B;
+    RtIdOut ids;
+    uint32_t xcd_chunk;
+};
+typedef const __attribute__((address_space(4))) FusedKernargs *FusedKernargsPtr;
+__device__ __forceinline__ const FusedKernargs &fresh(FusedKernargsPtr p) {
+    asm volatile("" : "+s"(p));
+    return *(const FusedKernargs *)p;
+}
+
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_FUSED_WAVES, RT_FUSED_WAVES)))
 k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
     extern __shared__ int32_t lds[];
-    const uint32_t count = Q.counters[RT_CNT_LIT];
-    const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
-    if (blockIdx.x >= n_blocks) return;
-    const uint32_t idx0 = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
-    const int rows = S.stack_depth + 1;
+    const FusedKernargsPtr args = (FusedKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t count, idx0;
+    int rows, n_point_lights;
+    bool want_ids, shadows;
+    {
+        const FusedKernargs &K = fresh(args);
+        // the layout assumed above, checked against two arguments as the compiler passes them
+        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != xcd_chunk) {
+            *Q.overflow = 1;
+            return;
+        }
+        count = K.Q.counters[RT_CNT_LIT];
+        const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
+        if (blockIdx.x >= n_blocks) return;
+        idx0 = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+        rows = K.S.stack_depth + 1;
+        n_point_lights = K.S.n_point_lights;
+        want_ids = K.ids.shadow_shape != nullptr || K.ids.shadow_tri != nullptr;
+        shadows = !K.S.disable_shadows;
+    }
     uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rows + 6 * 64) + threadIdx.x;  // behind the walk's LDS
     *hidden_slot = 0u;
-    const bool want_ids = ids.shadow_shape != nullptr || ids.shadow_tri != nullptr;
     bool ok = true;
-    if (!S.disable_shadows) {
-        for (int ls = 0; ls < S.n_point_lights; ++ls) {
+    if (shadows) {
+        for (int ls = 0; ls < n_point_lights; ++ls) {
             const uint32_t idx = opaque(idx0);
             const bool live = idx < count;
             FastTrav st[1];
             bool self = false;
             {
+                const FusedKernargs &K = fresh(args);
                 D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
                 int32_t org_shape = -1, org_tri = -1;
                 bool trace = false;
                 if (live) {
-                    const uint32_t sample = Q.lit_list[idx];
-                    org_shape = RT_STREAM_LD(Q.l_shape[sample]);
-                    org_tri = RT_STREAM_LD(Q.l_tri[sample]);
-                    self = ((RT_STREAM_LD(Q.l_self[sample]) >> ls) & 1u) != 0u;
+                    const uint32_t sample = K.Q.lit_list[idx];
+                    org_shape = RT_STREAM_LD(K.Q.l_shape[sample]);
+                    org_tri = RT_STREAM_LD(K.Q.l_tri[sample]);
+                    self = ((RT_STREAM_LD(K.Q.l_self[sample]) >> ls) & 1u) != 0u;
                     trace = !self;
                     if (trace) {
-                        o = lit_load_vec(Q.l_p, sample, true);  // the fused kernel is fast mode's
-                        d = d3(S.lights[S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
+                        o = lit_load_vec(K.Q.l_p, sample, true);  // the fused kernel is fast mode's
+                        d = d3(K.S.lights[K.S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
                     }
                 }
                 fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
@@ -309,22 +345,24 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
                 st[0].org_shape = org_shape;
                 st[0].org_tri = org_tri;
             }
-            ok = packet_traverse<true, 1>(S, st, (float)RT_VERY_SMALL_NUMBER, lds, rows - 1) && ok;
+            ok = packet_traverse<true, 1>(S, st, (float)RT_VERY_SMALL_NUMBER, lds, rows - 1) && ok;  // (the walk's fields of S stay in registers)
             if (st[0].shape >= 0 || self) *hidden_slot |= 1u << ls;
             if (want_ids && live) {
-                const uint32_t sample = Q.lit_list[opaque(idx0)];
-                const size_t at = global_sample(B, sample) * (size_t)S.n_point_lights + (size_t)ls;
-                const int32_t blocker = self ? RT_STREAM_LD(Q.l_shape[sample]) : st[0].shape;
-                if (ids.shadow_shape) ids.shadow_shape[at] = blocker;
-                if (ids.shadow_tri) ids.shadow_tri[at] = self ? -1 : tri_file_index(S, st[0].tri);
+                const FusedKernargs &K = fresh(args);
+                const uint32_t sample = K.Q.lit_list[opaque(idx0)];
+                const size_t at = global_sample(K.B, sample) * (size_t)n_point_lights + (size_t)ls;
+                const int32_t blocker = self ? RT_STREAM_LD(K.Q.l_shape[sample]) : st[0].shape;
+                if (K.ids.shadow_shape) K.ids.shadow_shape[at] = blocker;
+                if (K.ids.shadow_tri) K.ids.shadow_tri[at] = self ? -1 : tri_file_index(K.S, st[0].tri);
             }
         }
     }
-    if (!ok) *Q.overflow = 1;
+    const FusedKernargs &K = fresh(args);
+    if (!ok) *K.Q.overflow = 1;
     const uint32_t idx = opaque(idx0);
     if (idx < count) {
-        const uint32_t sample = Q.lit_list[idx];
-        accumulate_masked<true>(S, Q, sample, RT_STREAM_LD(Q.l_shape[sample]), *hidden_slot);  // fast mode only
+        const uint32_t sample = K.Q.lit_list[idx];
+        accumulate_masked<true>(K.S, K.Q, sample, RT_STREAM_LD(K.Q.l_shape[sample]), *hidden_slot);  // fast mode only
     }
 }
 
