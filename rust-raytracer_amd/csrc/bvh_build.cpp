@@ -589,6 +589,8 @@ std::string flatten_scene(const RtScene &scene, FlatScene &out, bool reference_m
                 const double bmin[3] = {s.bbox_min.x, s.bbox_min.y, s.bbox_min.z};
                 const double bmax[3] = {s.bbox_max.x, s.bbox_max.y, s.bbox_max.z};
                 box_to_f32(bmin, bmax, p.f, p.f + 3);
+                // the same box once more as per-axis (min, max) pairs, the operand shape of the packet walk's test
+                for (int c = 0; c < 3; ++c) { p.f[6 + 2 * c] = p.f[c]; p.f[7 + 2 * c] = p.f[3 + c]; }
             } else {
                 fill_payload(proto, p.f);
             }

@@ -313,7 +313,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         want_ids = K.ids.shadow_shape != nullptr || K.ids.shadow_tri != nullptr;
         shadows = !K.S.disable_shadows;
     }
-    uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rows + 6 * 64) + threadIdx.x;  // behind the walk's LDS
+    uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows)) + threadIdx.x;  // behind the walk's LDS
     *hidden_slot = 0u;
     bool ok = true;
     if (shadows) {
@@ -947,7 +947,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
     constexpr int packet_rays = 1;
     // stack rows, the world-space rays of a wave inside an instance, and (fused kernel) a word per lane
-    const size_t packet_lds = ((size_t)(std::max(S.stack_depth, 1) + 1) + 6u * 64u * (size_t)packet_rays + 64u) * sizeof(int32_t);
+    const size_t packet_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 64u) * sizeof(int32_t);  // + the fused kernel's word per lane
     // a wait per batch: to read the counters for the statistics, or to serve the progress callback
     const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
     const bool wait_batches = stats != nullptr || serve_progress;

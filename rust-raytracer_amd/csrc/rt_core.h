@@ -611,6 +611,19 @@ RT_HD void fast_set_ray(FastTrav &s, float ox, float oy, float oz, float dx, flo
     s.zin = rt_pair(iz, -(oz * iz));
 }
 
+// The world ray (wx, wy, wz: per-axis (origin, direction) pairs) in the space of an instance: through the
+// rows r0..r2 of its inverse transform (instance.rs:77-80), the translation reaching the origin only.
+// Each row meets the ray as two packed multiply-adds and a packed multiplication over the pairs, so origin
+// and direction advance together; every traversal path of the fast mode goes through this one function,
+// so they all see the same local ray.
+RT_HD void fast_set_ray_in_instance(FastTrav &s, const rt_f4 &r0, const rt_f4 &r1, const rt_f4 &r2, const rt_f2 &wx, const rt_f2 &wy,
+                                    const rt_f2 &wz) {
+    const rt_f2 x = rt_fma2(rt_pair(r0.x, r0.x), wx, rt_fma2(rt_pair(r0.y, r0.y), wy, rt_mul2(rt_pair(r0.z, r0.z), wz)));
+    const rt_f2 y = rt_fma2(rt_pair(r1.x, r1.x), wx, rt_fma2(rt_pair(r1.y, r1.y), wy, rt_mul2(rt_pair(r1.z, r1.z), wz)));
+    const rt_f2 z = rt_fma2(rt_pair(r2.x, r2.x), wx, rt_fma2(rt_pair(r2.y, r2.y), wy, rt_mul2(rt_pair(r2.z, r2.z), wz)));
+    fast_set_ray(s, x.x + r0.w, y.x + r1.w, z.x + r2.w, x.y, y.y, z.y);
+}
+
 // The stack keeps its top entry in a register: a pop hands that out at once and starts the
 // LDS read of the entry below, whose latency is then hidden behind the next node.
 template <class Stack>
@@ -698,6 +711,19 @@ RT_HD void fast_box2_signed(const FastTrav &s, const rt_f4 &a, const rt_f4 &b, c
     hr = er < xr;
 }
 
+// One box, given as per-axis (min, max) plane pairs, for a ray of known direction signs (fast_box's test
+// with the entry and exit plane of each slab picked at compile time): 3 packed multiply-adds, 2 max, 2 min
+// and a compare.
+template <int OCT>
+RT_HD bool fast_box_signed(const FastTrav &s, const rt_f2 &bx, const rt_f2 &by, const rt_f2 &bz, float tmin) {
+    const rt_f2 tx = rt_fma2(bx, rt_lo2(s.ixy), rt_lo2(s.nxy)), ty = rt_fma2(by, rt_hi2(s.ixy), rt_hi2(s.nxy));
+    const rt_f2 tz = rt_fma2(bz, rt_lo2(s.zin), rt_hi2(s.zin));
+    constexpr bool nx = (OCT & 1) != 0, ny = (OCT & 2) != 0, nz = (OCT & 4) != 0;
+    const float e = rt_fmax(rt_fmax(rt_fmax(nx ? tx.y : tx.x, ny ? ty.y : ty.x), nz ? tz.y : tz.x), tmin);
+    const float x = rt_fmin(rt_fmin(rt_fmin(nx ? tx.x : tx.y, ny ? ty.x : ty.y), nz ? tz.x : tz.y), s.t);
+    return e < x;
+}
+
 // Triangle::closest_hit (triangle.rs:66-110) through the triangle's affine map (RtTriXf):
 // t from the height row, then beta and gamma of the point at t.  Same acceptance rules:
 // t in [tmin, bound] closed, gamma in [0, 1], beta in [0, 1 - gamma]; a ray parallel to the
@@ -768,10 +794,7 @@ RT_HD void fast_local_ray(const RtSceneView &S, uint32_t slot, bool is_inst, flo
                           float wdy, float wdz, const FastTrav &w, FastTrav &out) {
     if (is_inst) {
         const rt_f4 *m = S.tprim_xf + (size_t)slot * 3;
-        const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
-        fast_set_ray(out, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w, ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
-                     ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w, (r0.x * wdx + r0.y * wdy) + r0.z * wdz,
-                     (r1.x * wdx + r1.y * wdy) + r1.z * wdz, (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+        fast_set_ray_in_instance(out, m[0], m[1], m[2], rt_pair(wox, wdx), rt_pair(woy, wdy), rt_pair(woz, wdz));
     } else {
         fast_set_ray(out, wox, woy, woz, wdx, wdy, wdz);
     }
@@ -853,13 +876,8 @@ RT_HD bool fast_step(const RtSceneView &S, FastTrav &s, Stack &stk, float tmin, 
                     fast_push(s, stk, RT_REF_EXIT_BLAS);
                     if (is_inst) {
                         const rt_f4 *m = S.tprim_xf + (size_t)(first + k) * 3;
-                        const rt_f4 r0 = m[0], r1 = m[1], r2 = m[2];
-                        const float wox = s.px.x, woy = s.py.x, woz = s.pz.x, wdx = s.px.y, wdy = s.py.y, wdz = s.pz.y;
-                        fast_set_ray(s, ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w,
-                                     ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
-                                     ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w,
-                                     (r0.x * wdx + r0.y * wdy) + r0.z * wdz, (r1.x * wdx + r1.y * wdy) + r1.z * wdz,
-                                     (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
+                        const rt_f2 wx = s.px, wy = s.py, wz = s.pz;
+                        fast_set_ray_in_instance(s, m[0], m[1], m[2], wx, wy, wz);
                     }
                     s.cur_shape = shape_id;
                     cur = blas_root;

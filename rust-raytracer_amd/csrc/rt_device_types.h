@@ -161,7 +161,8 @@ inline void rt_pixel_block(uint32_t tile_w, uint32_t tile_h, uint32_t samples_pe
 //   BOX       f[0..2] min, f[3..5] max
 //   TRIANGLE  f[0..2] a, f[3..5] a-b, f[6..8] a-c
 //   MESH      blas_root = header node of the mesh's tree, tri_base = first triangle
-//   INSTANCE  proto_type + the prototype's payload as above (object space)
+//   INSTANCE  proto_type + the prototype's payload as above (object space); of a mesh: f[0..2] min, f[3..5] max of
+//             the instance's world box, f[6..11] the same box as (min, max) pairs per axis
 struct RtTPrim {
     int32_t type;       // RT_SHAPE_*
     int32_t shape_id;   // index into RtScene.shapes

@@ -54,16 +54,13 @@ struct WaveStack {
 // smaller centroids left).  Bit 3: the rays do NOT all agree on all three axes.  "Runs towards
 // smaller coordinates" is read off the clamped 1/d the box test multiplies with, so that it is
 // also defined for d = +-0.
-template <int R>
-__device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav (&s)[R], const bool (&live)[R]) {
-    int n = 0, nx = 0, ny = 0, nz = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        n += __popcll(__ballot(live[r]));
-        nx += __popcll(__ballot(live[r] && s[r].ixy.x < 0.0f));
-        ny += __popcll(__ballot(live[r] && s[r].ixy.y < 0.0f));
-        nz += __popcll(__ballot(live[r] && s[r].zin.x < 0.0f));
-    }
+// `live`: the ballot of the lanes that hold a ray (taken once per traversal; combining it with the sign tests
+// as lane masks in scalar registers keeps each test at one vector compare).
+__device__ __forceinline__ uint32_t packet_direction_bits(const FastTrav &s, unsigned long long live) {
+    const int n = __popcll(live);
+    const int nx = __popcll(__ballot(s.ixy.x < 0.0f) & live);
+    const int ny = __popcll(__ballot(s.ixy.y < 0.0f) & live);
+    const int nz = __popcll(__ballot(s.zin.x < 0.0f) & live);
     const int half = n >> 1;
     const bool mixed = (nx != 0 && nx != n) || (ny != 0 && ny != n) || (nz != 0 && nz != n);
     return (nx > half ? 1u : 0u) | (ny > half ? 2u : 0u) | (nz > half ? 4u : 0u) | (mixed ? 8u : 0u);
@@ -530,11 +527,18 @@ __device__ __forceinline__ int32_t packet_blas_asm(const RtSceneView &S, FastTra
 }
 #endif
 
+// LDS of one wave: the stack's rows (padded to an even number of dwords), then the world-space ray as six
+// (x, y) pairs per lane -- px, py, pz, ixy, nxy, zin of FastTrav -- where it waits while the wave is inside
+// a mesh; a kernel's own words follow at rt_packet_lds_dwords().
+#define RT_PACKET_WORLD_DWORDS (12 * 64)
+inline __host__ __device__ uint32_t rt_packet_world_offset(int rows) { return ((uint32_t)rows + 1u) & ~1u; }
+inline __host__ __device__ uint32_t rt_packet_lds_dwords(int rows) { return rt_packet_world_offset(rows) + RT_PACKET_WORLD_DWORDS; }
+
 // Traverses the scene with the wave's 64 rays (R = 1: one per lane; more per lane was measured and
 // dropped).  On entry s[0] holds the lane's world-space ray, search bound s[0].t (-inf for a slot
 // without a ray), s[0].shape / .tri = initial hit, and the origin primitive.  `lds_rows`: max_sp + 1
-// dwords for the stack, followed by 6 * 64 floats in which the world-space ray waits while the wave is
-// inside a mesh.  Returns false on stack overflow.
+// dwords for the stack, followed by the world-space ray (see rt_packet_lds_dwords).  Returns false on
+// stack overflow.
 //
 // Two levels, two ray variables.  The outer loop walks the scene-level tree with the world ray and
 // never changes it.  A mesh (or instanced mesh) found in a scene-level leaf is traversed then and
@@ -549,11 +553,11 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
     static_assert(R == 1, "one ray per lane");
     constexpr bool ORDERED = !ANYHIT || RT_ANYHIT_ORDERED;
     const float ninf = -__builtin_inff();
-    float *world = reinterpret_cast<float *>(lds_rows + max_sp + 1) + (threadIdx.x & 63u);  // [6][64]
-    bool live[1] = {s[0].t > ninf};
-    world[0 * 64] = s[0].px.x; world[1 * 64] = s[0].py.x; world[2 * 64] = s[0].pz.x;
-    world[3 * 64] = s[0].px.y; world[4 * 64] = s[0].py.y; world[5 * 64] = s[0].pz.y;
-    const uint32_t world_bits = packet_direction_bits<1>(s, live);
+    rt_f2 *world = reinterpret_cast<rt_f2 *>(lds_rows + rt_packet_world_offset(max_sp + 1)) + (threadIdx.x & 63u);  // [6][64] pairs
+    const unsigned long long live = __ballot(s[0].t > ninf);
+    world[0 * 64] = s[0].px; world[1 * 64] = s[0].py; world[2 * 64] = s[0].pz;
+    world[3 * 64] = s[0].ixy; world[4 * 64] = s[0].nxy; world[5 * 64] = s[0].zin;
+    const uint32_t world_bits = packet_direction_bits(s[0], live);
     WaveStack stk;
     stk.init(lds_rows);
     int32_t cur = S.tlas_root;
@@ -588,8 +592,23 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
             if (type == RT_SHAPE_MESH || (is_inst && proto_type == RT_SHAPE_MESH)) {
                 if (is_inst) {
                     // enter the instance only if some ray of the wave reaches its world box
-                    float e;
-                    if (__ballot(fast_box(s[0], pp1.x, pp1.y, pp1.z, pp1.w, pp2.x, pp2.y, tmin, e)) == 0ull) continue;
+                    const rt_f2 bx = rt_pair(pp2.z, pp2.w), by = rt_pair(pp3.x, pp3.y), bz = rt_pair(pp3.z, pp3.w);
+                    bool reach;
+                    switch (world_bits) {
+                    case 0: reach = fast_box_signed<0>(s[0], bx, by, bz, tmin); break;
+                    case 1: reach = fast_box_signed<1>(s[0], bx, by, bz, tmin); break;
+                    case 2: reach = fast_box_signed<2>(s[0], bx, by, bz, tmin); break;
+                    case 3: reach = fast_box_signed<3>(s[0], bx, by, bz, tmin); break;
+                    case 4: reach = fast_box_signed<4>(s[0], bx, by, bz, tmin); break;
+                    case 5: reach = fast_box_signed<5>(s[0], bx, by, bz, tmin); break;
+                    case 6: reach = fast_box_signed<6>(s[0], bx, by, bz, tmin); break;
+                    case 7: reach = fast_box_signed<7>(s[0], bx, by, bz, tmin); break;
+                    default: {
+                        float e;
+                        reach = fast_box(s[0], pp1.x, pp1.y, pp1.z, pp1.w, pp2.x, pp2.y, tmin, e);
+                    }
+                    }
+                    if (__ballot(reach) == 0ull) continue;
                 }
                 // the ray in the mesh's space, with the hit so far
                 FastTrav m[1];
@@ -597,11 +616,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                 if (is_inst) {
                     rt_f4 r0, r1, r2;
                     rt_fetch_48(S.tprim_xf, (first + k) * 48u, r0, r1, r2);
-                    const float wox = s[0].px.x, woy = s[0].py.x, woz = s[0].pz.x, wdx = s[0].px.y, wdy = s[0].py.y, wdz = s[0].pz.y;
-                    fast_set_ray(m[0], ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w, ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w,
-                                 ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w, (r0.x * wdx + r0.y * wdy) + r0.z * wdz,
-                                 (r1.x * wdx + r1.y * wdy) + r1.z * wdz, (r2.x * wdx + r2.y * wdy) + r2.z * wdz);
-                    bits = packet_direction_bits<1>(m, live);
+                    fast_set_ray_in_instance(m[0], r0, r1, r2, s[0].px, s[0].py, s[0].pz);
+                    bits = packet_direction_bits(m[0], live);
                 } else {
                     m[0].px = s[0].px; m[0].py = s[0].py; m[0].pz = s[0].pz;
                     m[0].ixy = s[0].ixy; m[0].nxy = s[0].nxy; m[0].zin = s[0].zin;
@@ -661,7 +677,8 @@ __device__ __forceinline__ bool packet_traverse(const RtSceneView &S, FastTrav (
                 s[0].tri = m[0].tri;
                 done = c == RT_REF_NONE;  // an any-hit wave with no lane left looking
                 // the world ray again, for the rest of this leaf and the walk after it
-                fast_set_ray(s[0], world[0 * 64], world[1 * 64], world[2 * 64], world[3 * 64], world[4 * 64], world[5 * 64]);
+                s[0].px = world[0 * 64]; s[0].py = world[1 * 64]; s[0].pz = world[2 * 64];
+                s[0].ixy = world[3 * 64]; s[0].nxy = world[4 * 64]; s[0].zin = world[5 * 64];
             } else {
                 // sphere / box / triangle at scene level, possibly instanced
                 float t;
