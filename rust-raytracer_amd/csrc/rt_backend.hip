@@ -200,9 +200,14 @@ k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_sampl
 // 64 consecutive samples, so loads and stores stay coalesced.
 template <int KIND, int R>
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
-k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk) {
+k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk, uint32_t n_clear) {
     extern __shared__ int32_t lds[];
     constexpr uint32_t per_block = RT_PACKET_BLOCK * R;
+    // As a batch's first kernel (camera rays) it also zeroes the batch's counters and per-chunk lit counts,
+    // which the stages behind it add to: a store by the first few waves instead of a memset (two more
+    // launches in front of every frame).  n_clear = 0: the caller has cleared them.
+    if (KIND == 0)
+        for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < n_clear; i += gridDim.x * RT_PACKET_BLOCK) Q.counters[i] = 0u;
     const uint32_t count = KIND == 1 ? Q.counters[RT_CNT_LIT] : n_samples;
     const uint32_t n_blocks = (count + per_block - 1) / per_block;  // blocks that have work; the rest leave
     if (blockIdx.x >= n_blocks) return;
@@ -971,7 +976,11 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         const uint32_t n_samples = B.n_pixels * spp;
 
         const uint32_t lit_grid = (n_samples + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
-        RT_HIP(hipMemsetAsync(Q.counters, 0, ((size_t)RT_CNT_SIZE + lit_grid) * sizeof(uint32_t), stream));
+        // counters and per-chunk lit counts start at zero: cleared by the camera-ray packet kernel where that
+        // is the batch's first kernel, by a memset otherwise
+        const uint32_t n_counters = (uint32_t)RT_CNT_SIZE + lit_grid;
+        const bool clear_in_kernel = !ds->has_ggx && !ref_order && use_packets;
+        if (!clear_in_kernel) RT_HIP(hipMemsetAsync(Q.counters, 0, (size_t)n_counters * sizeof(uint32_t), stream));
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
@@ -995,7 +1004,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             else if (bounce == 0 && use_packets)
-                hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
+                hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, bounce == 0 && clear_in_kernel ? n_counters : 0u);
             else
                 hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
@@ -1024,7 +1033,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                     if (ref_order)
                         hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
                     else if (use_packets)
-                        hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk);
+                        hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, 0u);
                     else
                         hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
                     tm.end();
