@@ -300,6 +300,9 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
                          uint32_t idx, MirrorTmp &tmp) {
     D3 o, d;
     int32_t sample;
+    // the hit record first: its loads are then in flight while the camera ray is computed again
+    const int32_t shape = RT_STREAM_LD(Q.h_shape[idx]), gtri = RT_STREAM_LD(Q.h_tri[idx]);
+    const float hit_t = RT_STREAM_LD(Q.h_t[idx]);
     if (bounce == 0) {
         sample = (int32_t)idx;
         Q.l_shape[sample] = -1;  // every sample passes here exactly once: this clears the lit table
@@ -309,7 +312,6 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         sample = Q.q_sample[which][idx];
         queue_read_ray(Q, which, idx, o, d);
     }
-    const int32_t shape = RT_STREAM_LD(Q.h_shape[idx]), gtri = RT_STREAM_LD(Q.h_tri[idx]);
     const bool want_ids = ids.primary_shape || ids.primary_tri || ids.final_shape || ids.final_tri || ids.bounces;
     const size_t gs = want_ids ? global_sample(B, (uint32_t)sample) : 0;
     const int32_t ftri = tri_file_index(S, gtri);
@@ -325,7 +327,7 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         return RT_ACT_NONE;
     }
     const double tmin = bounce == 0 ? 1.0 : RT_VERY_SMALL_NUMBER;
-    double t = (double)RT_STREAM_LD(Q.h_t[idx]);
+    double t = (double)hit_t;
     D3 n;
     exact_prim_hit(S, shape, gtri, o, d, tmin, (double)__builtin_inff(), true, t, t, &n);
     const D3 p = o + d * t;  // Hit::hit_point, hit_struct.rs:41-43
