@@ -434,8 +434,16 @@ __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scan(RtBuffers Q, uint32
     if (threadIdx.x == RT_LIT_THREADS - 1) Q.counters[RT_CNT_LIT] = part[RT_LIT_THREADS - 1];
 }
 
+// OWN_OFFSET: no scan has run; block_counts still holds the counts, and every block adds up those of the
+// chunks in front of it by itself (the last one also leaves the total in counters[RT_CNT_LIT]).  For a grid
+// of a thousand chunks -- an eighth of a frame -- that is four loads per thread and one launch fewer on the
+// frame's critical path; for a whole frame's 8800 chunks the sums would move more data than the scatter
+// itself, and the scan kernel stays.
+#define RT_LIT_OWN_OFFSET_MAX 2048u
+template <bool OWN_OFFSET>
 __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
     __shared__ uint32_t wave_total[RT_LIT_ROUNDS][RT_LIT_THREADS / 64];
+    __shared__ uint32_t before[RT_LIT_THREADS / 64];
     const uint32_t wave = threadIdx.x >> 6;
     bool lit[RT_LIT_ROUNDS];
     uint32_t rank[RT_LIT_ROUNDS];
@@ -446,15 +454,28 @@ __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scatter(RtBuffers Q, uin
         rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if ((threadIdx.x & 63u) == 0) wave_total[r][wave] = (uint32_t)__popcll(mask);
     }
+    if (OWN_OFFSET) {
+        uint32_t acc = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += RT_LIT_THREADS) acc += Q.block_counts[b];
+        for (int d = 32; d > 0; d >>= 1) acc += (uint32_t)__shfl_down((int)acc, d, 64);
+        if ((threadIdx.x & 63u) == 0) before[wave] = acc;
+    }
     __syncthreads();
     // samples of a chunk are ordered round by round, wave by wave inside a round
-    uint32_t off = Q.block_counts[blockIdx.x];
+    uint32_t off;
+    if (OWN_OFFSET) {
+        off = 0;
+        for (uint32_t w = 0; w < RT_LIT_THREADS / 64; ++w) off += before[w];
+    } else {
+        off = Q.block_counts[blockIdx.x];
+    }
     for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
         for (uint32_t w = 0; w < RT_LIT_THREADS / 64; ++w) {
             if (w == wave && lit[r]) Q.lit_list[off + rank[r]] = blockIdx.x * RT_LIT_BLOCK + r * RT_LIT_THREADS + threadIdx.x;
             off += wave_total[r][w];
         }
     }
+    if (OWN_OFFSET && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) Q.counters[RT_CNT_LIT] = off;
 }
 
 // Work item = (point light blockIdx.y, lit entry): consecutive lanes are neighbouring
@@ -1017,8 +1038,12 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         }
         if (ds->has_lit) {
             if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
-            hipLaunchKernelGGL(k_lit_scatter, dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+            if (lit_grid <= RT_LIT_OWN_OFFSET_MAX) {
+                hipLaunchKernelGGL((k_lit_scatter<true>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+            } else {
+                hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
+                hipLaunchKernelGGL((k_lit_scatter<false>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+            }
             tm.end();
             // the number of lit hits is only known on the device: size the grids for the worst
             // case, surplus blocks return at once
