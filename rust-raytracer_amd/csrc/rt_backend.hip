@@ -437,9 +437,12 @@ __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scan(RtBuffers Q, uint32
 // OWN_OFFSET: no scan has run; block_counts still holds the counts, and every block adds up those of the
 // chunks in front of it by itself (the last one also leaves the total in counters[RT_CNT_LIT]).  For a grid
 // of a thousand chunks -- an eighth of a frame -- that is four loads per thread and one launch fewer on the
-// frame's critical path; for a whole frame's 8800 chunks the sums would move more data than the scatter
-// itself, and the scan kernel stays.
-#define RT_LIT_OWN_OFFSET_MAX 2048u
+// frame's critical path (every 1/8 part of the bunny frame: 0.1115 -> 0.109 ms).  For a whole frame's 8800
+// chunks the sums move more data than the scatter itself: one frame at a time gains 0.5 %, four in flight
+// lose 0.3 %, and the scan kernel stays.
+#ifndef RT_LIT_OWN_OFFSET_MAX
+#define RT_LIT_OWN_OFFSET_MAX 4608u
+#endif
 template <bool OWN_OFFSET>
 __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scatter(RtBuffers Q, uint32_t n_samples) {
     __shared__ uint32_t wave_total[RT_LIT_ROUNDS][RT_LIT_THREADS / 64];
