@@ -192,12 +192,14 @@ k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_sampl
 
 // Packet form of the same two kernels (rt_packet.h): a wave traverses with its 64 rays together.
 // Used for camera rays and shadow rays, whose neighbours in a wave are neighbouring samples.
-// Dynamic LDS: one uniform stack of (stack_depth + 1) dwords per wave.  One wave per block: the
+// Dynamic LDS: one uniform stack of (stack_depth + 1) dwords per wave and the parked world ray
+// (rt_packet_lds_dwords).  One wave per block: the
 // waves share nothing, and their run times differ widely (a wave whose rays all miss the
 // meshes is done in a few steps), so a block of four would hold its slots for the slowest
 // (measured on the bunny frame: 0.51 -> 0.39 ms camera rays, 1.08 -> 0.96 ms shadow rays).
 // R rays per lane: lane l of block b holds work items (b * R + r) * 64 + l, r < R -- each r a run of
-// 64 consecutive samples, so loads and stores stay coalesced.
+// 64 consecutive samples, so loads and stores stay coalesced.  (Only R = 1 is built: two rays per lane
+// were measured and dropped, and the traversal is written for one.)
 template <int KIND, int R>
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, RT_PACKET_WAVES)))
 k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk, uint32_t n_clear) {

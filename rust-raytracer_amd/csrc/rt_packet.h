@@ -17,7 +17,7 @@
 // This is exactly the per-lane traversal's result (closest hit is order independent, box
 // tests only cull); what changes is the cost.  Camera rays and shadow rays of neighbouring
 // samples touch nearly the same nodes (measured on the 1000x1000 bunny frame: a wave's union
-// is 15 nodes for camera rays against 12.6 for its longest lane, 24..30 against 18..23 for
+// is 14 nodes for camera rays against 12.6 for its longest lane, 21..25 against 17..21 for
 // shadow rays), so the packet executes about as many steps as its slowest lane did alone,
 // without the divergence, the per-lane stack traffic and 4 KiB of vector loads per step.
 // Incoherent rays (mirror bounces) keep the per-lane kernel.
