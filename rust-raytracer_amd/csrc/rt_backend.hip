@@ -190,6 +190,37 @@ k_trace_fast(RtSceneView S, RtBuffers Q, RtBatch B, int bounce, uint32_t n_sampl
     else trace_closest_fast_body<LdsStack>(S, Q, B, bounce, idx, stk);
 }
 
+// A kernel's arguments as they lie in its argument segment (by-value arguments follow one another at
+// their natural alignment, like the members of a struct).  The compiler loads every argument field a
+// kernel uses into scalar registers at the top and keeps it there; the packet kernels use dozens of
+// pointers but have fifty-odd scalar registers besides the walk's, so most of them were parked in lanes of
+// a vector register and read back, one vector instruction per register, wherever they were needed again
+// (an eighth of the fused kernel's vector instructions, a tenth of the camera-ray kernel's).  Fields that
+// the walk itself does not need are therefore read where they are used, through a pointer to the argument
+// segment that the compiler cannot see through (`fresh`): scalar loads that hit the scalar cache, and no
+// long-lived registers.  Each kernel checks the assumed layout against two of its arguments as the
+// compiler passes them, and reports a failed frame if they disagree.
+struct PacketKernargs {
+    RtSceneView S;
+    RtBuffers Q;
+    RtBatch B;
+    uint32_t n_samples, xcd_chunk, n_clear;
+};
+struct FusedKernargs {
+    RtSceneView S;
+    RtBuffers Q;
+    RtBatch B;
+    RtIdOut ids;
+    uint32_t xcd_chunk;
+};
+template <class T>
+__device__ __forceinline__ const T &fresh(const __attribute__((address_space(4))) T *p) {
+    asm volatile("" : "+s"(p));
+    return *(const T *)p;
+}
+typedef const __attribute__((address_space(4))) PacketKernargs *PacketKernargsPtr;
+typedef const __attribute__((address_space(4))) FusedKernargs *FusedKernargsPtr;
+
 // Packet form of the same two kernels (rt_packet.h): a wave traverses with its 64 rays together.
 // Used for camera rays and shadow rays, whose neighbours in a wave are neighbouring samples.
 // Dynamic LDS: one uniform stack of (stack_depth + 1) dwords per wave and the parked world ray
@@ -205,31 +236,42 @@ __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_p
 k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32_t xcd_chunk, uint32_t n_clear) {
     extern __shared__ int32_t lds[];
     constexpr uint32_t per_block = RT_PACKET_BLOCK * R;
-    // As a batch's first kernel (camera rays) it also zeroes the batch's counters and per-chunk lit counts,
-    // which the stages behind it add to: a store by the first few waves instead of a memset (two more
-    // launches in front of every frame).  n_clear = 0: the caller has cleared them.
-    if (KIND == 0)
-        for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < n_clear; i += gridDim.x * RT_PACKET_BLOCK) Q.counters[i] = 0u;
-    const uint32_t count = KIND == 1 ? Q.counters[RT_CNT_LIT] : n_samples;
-    const uint32_t n_blocks = (count + per_block - 1) / per_block;  // blocks that have work; the rest leave
-    if (blockIdx.x >= n_blocks) return;
-    const uint32_t base = xcd_chunked_block(blockIdx.x, n_blocks, xcd_chunk * RT_BLOCK / per_block) * per_block + threadIdx.x;
-    const int rows = S.stack_depth + 1;
+    const PacketKernargsPtr args = (PacketKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t count, base;
+    int rows;
+    {
+        const PacketKernargs &K = fresh(args);
+        if (K.Q.lit_list != Q.lit_list || K.n_clear != n_clear) {  // the layout assumed for the argument segment
+            *Q.overflow = 1;
+            return;
+        }
+        // As a batch's first kernel (camera rays) it also zeroes the batch's counters and per-chunk lit counts,
+        // which the stages behind it add to: a store by the first few waves instead of a memset (two more
+        // launches in front of every frame).  n_clear = 0: the caller has cleared them.
+        if (KIND == 0)
+            for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < K.n_clear; i += gridDim.x * RT_PACKET_BLOCK) K.Q.counters[i] = 0u;
+        count = KIND == 1 ? K.Q.counters[RT_CNT_LIT] : K.n_samples;
+        const uint32_t n_blocks = (count + per_block - 1) / per_block;  // blocks that have work; the rest leave
+        if (blockIdx.x >= n_blocks) return;
+        base = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / per_block) * per_block + threadIdx.x;
+        rows = K.S.stack_depth + 1;
+    }
     FastTrav st[R];
     uint32_t sample[R];
     bool live[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
+        const PacketKernargs &K = fresh(args);
         const uint32_t idx = base + (uint32_t)k * RT_PACKET_BLOCK;
         RaySetup r;
         sample[k] = 0;
         live[k] = idx < count;
         if (live[k]) {
             if (KIND == 1) {
-                sample[k] = Q.lit_list[idx];
-                live[k] = shadow_setup_lit(S, Q, blockIdx.y, sample[k], r);
+                sample[k] = K.Q.lit_list[idx];
+                live[k] = shadow_setup_lit(K.S, K.Q, blockIdx.y, sample[k], r);
             } else {
-                live[k] = closest_setup(S, Q, B, 0, idx, r);
+                live[k] = closest_setup(K.S, K.Q, K.B, 0, idx, r);
             }
         }
         if (!live[k]) {  // a slot without a ray: finite dummy values and an empty search interval
@@ -247,13 +289,14 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
         st[k].org_tri = r.org_tri;
     }
     const float tmin = KIND == 1 ? (float)RT_VERY_SMALL_NUMBER : closest_tmin(0);
-    const bool ok = packet_traverse<KIND == 1, R>(S, st, tmin, lds, rows - 1);
-    if (!ok) *Q.overflow = 1;
+    const bool ok = packet_traverse<KIND == 1, R>(S, st, tmin, lds, rows - 1);  // (the walk's fields of S stay in registers)
+    const PacketKernargs &K = fresh(args);
+    if (!ok) *K.Q.overflow = 1;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (!live[k]) continue;
-        if (KIND == 1) shadow_store(Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
-        else closest_store(Q, base + (uint32_t)k * RT_PACKET_BLOCK, st[k].t, st[k].shape, st[k].tri);
+        if (KIND == 1) shadow_store(K.Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
+        else closest_store(K.Q, base + (uint32_t)k * RT_PACKET_BLOCK, st[k].t, st[k].shape, st[k].tri);
     }
 }
 
@@ -274,27 +317,6 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
 __device__ __forceinline__ uint32_t opaque(uint32_t v) {
     asm volatile("" : "+v"(v));
     return v;
-}
-
-// The kernel's arguments as they lie in its argument segment (by-value arguments follow one another
-// at their natural alignment, like the members of a struct).  The compiler loads every argument field a
-// kernel uses into scalar registers at the top and keeps it there; this kernel uses some forty pointers
-// but has fifty-odd scalar registers besides the walk's, so most of them were parked in lanes of a vector
-// register and read back, one vector instruction per register, once per light and again after the walk
-// (an eighth of the kernel's vector instructions).  Fields that the walk itself does not need are
-// therefore read where they are used, through a pointer to the argument segment that the compiler
-// cannot see through (`fresh`): scalar loads that hit the scalar cache, and no long-lived registers.
-struct FusedKernargs {
-    RtSceneView S;
-    RtBuffers Q;
-    RtBatch B;
-    RtIdOut ids;
-    uint32_t xcd_chunk;
-};
-typedef const __attribute__((address_space(4))) FusedKernargs *FusedKernargsPtr;
-__device__ __forceinline__ const FusedKernargs &fresh(FusedKernargsPtr p) {
-    asm volatile("" : "+s"(p));
-    return *(const FusedKernargs *)p;
 }
 
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_FUSED_WAVES, RT_FUSED_WAVES)))
