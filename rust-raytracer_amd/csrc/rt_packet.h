@@ -193,18 +193,17 @@ __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastT
     "s_cselect_b32 s49, s60, s61\n\t"                               \
     "s_cselect_b64 s[50:51], s[56:57], s[54:55]\n\t"                \
     "s_cselect_b64 s[52:53], s[54:55], s[56:57]\n\t"
-#define RT_WALK_LEFT_FIRST                                          \
-    "s_mov_b32 s48, s60\n\t"                                        \
-    "s_mov_b32 s49, s61\n\t"                                        \
-    "s_mov_b64 s[50:51], s[54:55]\n\t"                              \
-    "s_mov_b64 s[52:53], s[56:57]\n\t"
+// The order of a node's children as five macro arguments: the instructions that establish it, then the
+// registers that hold the first and second child's reference and ballot.  Left first: the record's own
+// registers and the compares' results serve as they are.
+#define RT_ORDER_OCT(OCT) RT_WALK_ORDERED(OCT), "s48", "s49", "s[50:51]", "s[52:53]"
+#define RT_ORDER_LEFT "", "s60", "s61", "s[54:55]", "s[56:57]"
 // E_* / X_*: the register of each plane pair that holds the entry / exit distance (left and right box)
-#define RT_WALK_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER)                      \
+#define RT_WALK_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER, FIRST, SECOND, FIRST_BAL, SECOND_BAL)                      \
     "1:\n\t"                                                                                                             \
     "s_load_dwordx8 s[48:55], %[nb], %[cur]\n\t"                                                                         \
     "s_load_dwordx8 s[56:63], %[nb], %[cur] offset:0x20\n\t"                                                             \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
-    "s_nop 0\n\t"                                                                                                        \
     "v_pk_fma_f32 v[48:49], s[48:49], %[ixy], %[nxy] op_sel_hi:[1,0,0]\n\t"                                              \
     "v_pk_fma_f32 v[50:51], s[50:51], %[ixy], %[nxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                               \
     "v_pk_fma_f32 v[52:53], s[56:57], %[zin], %[zin] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                               \
@@ -221,22 +220,22 @@ __device__ __forceinline__ int32_t packet_walk(const RtSceneView &S, const FastT
     "v_max3_f32 v60, v60, " E_RZ ", %[tmin]\n\t"                                                                         \
     "v_min3_f32 v61, v61, " X_RZ ", %[t]\n\t"                                                                            \
     "v_cmp_lt_f32_e64 s[56:57], v60, v61\n\t"                                                                            \
-    ORDER /* s48 / s49 = first / second child, s[50:51] / s[52:53] = their ballots */                                    \
-    "s_cmp_lg_u64 s[50:51], 0\n\t"                                                                                       \
+    ORDER /* FIRST / SECOND = first / second child, FIRST_BAL / SECOND_BAL = their ballots */                            \
+    "s_cmp_lg_u64 " FIRST_BAL ", 0\n\t"                                                                                       \
     "s_cbranch_scc0 3f\n\t"                                                                                              \
-    "s_mov_b32 %[cur], s48\n\t"                                                                                          \
-    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_mov_b32 %[cur], " FIRST "\n\t"                                                                                          \
+    "s_cmp_lg_u64 " SECOND_BAL ", 0\n\t"                                                                                       \
     "s_cbranch_scc0 5f\n\t"                                                                                              \
     "s_lshl2_add_u32 s58, %[sp], %[base]\n\t" /* both: push the second */                                                \
     "v_mov_b32 v60, s58\n\t"                                                                                             \
     "ds_write_b32 v60, %[tos]\n\t"                                                                                       \
     "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                      \
     "s_max_i32 %[high], %[high], %[sp]\n\t"                                                                              \
-    "v_mov_b32 %[tos], s49\n\t"                                                                                          \
+    "v_mov_b32 %[tos], " SECOND "\n\t"                                                                                          \
     "s_branch 5f\n"                                                                                                      \
     "3:\n\t"                                                                                                             \
-    "s_mov_b32 %[cur], s49\n\t"                                                                                          \
-    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_mov_b32 %[cur], " SECOND "\n\t"                                                                                          \
+    "s_cmp_lg_u64 " SECOND_BAL ", 0\n\t"                                                                                       \
     "s_cbranch_scc1 5f\n\t"                                                                                              \
     "v_readfirstlane_b32 %[cur], %[tos]\n\t" /* neither: pop */                                                          \
     "s_sub_i32 %[sp], %[sp], 1\n\t"                                                                                      \
@@ -279,8 +278,8 @@ __device__ __forceinline__ int32_t packet_walk_asm(const RtSceneView &S, const F
     cur = __builtin_amdgcn_readfirstlane(cur);
 #define RT_WALK_CASE(N, X, Y, Z)                                                       \
     if constexpr (OCT == N) {                                                          \
-        if constexpr (ORDERED) RT_WALK_RUN(RT_WALK_ASM(X, Y, Z, RT_WALK_ORDERED(#N))); \
-        else RT_WALK_RUN(RT_WALK_ASM(X, Y, Z, RT_WALK_LEFT_FIRST));                    \
+        if constexpr (ORDERED) RT_WALK_RUN(RT_WALK_ASM(X, Y, Z, RT_ORDER_OCT(#N))); \
+        else RT_WALK_RUN(RT_WALK_ASM(X, Y, Z, RT_ORDER_LEFT));                    \
     }
     RT_WALK_CASE(0, RT_WALK_X_POS, RT_WALK_Y_POS, RT_WALK_Z_POS)
     RT_WALK_CASE(1, RT_WALK_X_NEG, RT_WALK_Y_POS, RT_WALK_Z_POS)
@@ -313,7 +312,6 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
     asm("s_load_dwordx8 s[48:55], %[tb], %[at]\n\t"
         "s_load_dwordx4 s[56:59], %[tb], %[at] offset:0x20\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "s_nop 0\n\t"
         "v_pk_mul_f32 v[48:49], %[pz], s[58:59] op_sel_hi:[1,0]\n\t"                             // n.z * (oz, dz)
         "v_pk_fma_f32 v[48:49], %[py], s[56:57], v[48:49] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"  // + n.y * (oy, dy)
         "v_pk_fma_f32 v[48:49], %[px], s[56:57], v[48:49] op_sel_hi:[1,0,1]\n\t"                 // + n.x * (ox, dx)
@@ -353,14 +351,14 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
 // instructions; the load of the leaf's next record into the same registers is issued right after them, so
 // that its latency passes behind the acceptance tests instead of in front of the next triangle.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define RT_BLAS_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER, TAKE_T, LEAF_END)    \
+#define RT_BLAS_ASM_(E_LX, X_LX, E_RX, X_RX, E_LY, X_LY, E_RY, X_RY, E_LZ, X_LZ, E_RZ, X_RZ, ORDER, FIRST, SECOND, FIRST_BAL, SECOND_BAL, \
+                     TAKE_T, LEAF_END)    \
     "s_cmp_lt_i32 %[cur], 0\n\t"                                                                                         \
     "s_cbranch_scc1 7f\n"                                                                                                \
     "1:\n\t"                                                                                                             \
     "s_load_dwordx8 s[48:55], %[nb], %[cur]\n\t"                                                                         \
     "s_load_dwordx8 s[56:63], %[nb], %[cur] offset:0x20\n\t"                                                             \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
-    "s_nop 0\n\t"                                                                                                        \
     "v_pk_fma_f32 v[48:49], s[48:49], %[ixy], %[nxy] op_sel_hi:[1,0,0]\n\t"                                              \
     "v_pk_fma_f32 v[50:51], s[50:51], %[ixy], %[nxy] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                               \
     "v_pk_fma_f32 v[52:53], s[56:57], %[zin], %[zin] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                               \
@@ -377,22 +375,22 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
     "v_max3_f32 v60, v60, " E_RZ ", %[tmin]\n\t"                                                                         \
     "v_min3_f32 v61, v61, " X_RZ ", %[t]\n\t"                                                                            \
     "v_cmp_lt_f32_e64 s[56:57], v60, v61\n\t"                                                                            \
-    ORDER /* s48 / s49 = first / second child, s[50:51] / s[52:53] = their ballots */                                    \
-    "s_cmp_lg_u64 s[50:51], 0\n\t"                                                                                       \
+    ORDER /* FIRST / SECOND = first / second child, FIRST_BAL / SECOND_BAL = their ballots */                            \
+    "s_cmp_lg_u64 " FIRST_BAL ", 0\n\t"                                                                                       \
     "s_cbranch_scc0 3f\n\t"                                                                                              \
-    "s_mov_b32 %[cur], s48\n\t"                                                                                          \
-    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_mov_b32 %[cur], " FIRST "\n\t"                                                                                          \
+    "s_cmp_lg_u64 " SECOND_BAL ", 0\n\t"                                                                                       \
     "s_cbranch_scc0 5f\n\t"                                                                                              \
     "s_lshl2_add_u32 s58, %[sp], %[base]\n\t" /* both: push the second */                                                \
     "v_mov_b32 v60, s58\n\t"                                                                                             \
     "ds_write_b32 v60, %[tos]\n\t"                                                                                       \
     "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                      \
     "s_max_i32 %[high], %[high], %[sp]\n\t"                                                                              \
-    "v_mov_b32 %[tos], s49\n\t"                                                                                          \
+    "v_mov_b32 %[tos], " SECOND "\n\t"                                                                                          \
     "s_branch 5f\n"                                                                                                      \
     "3:\n\t"                                                                                                             \
-    "s_mov_b32 %[cur], s49\n\t"                                                                                          \
-    "s_cmp_lg_u64 s[52:53], 0\n\t"                                                                                       \
+    "s_mov_b32 %[cur], " SECOND "\n\t"                                                                                          \
+    "s_cmp_lg_u64 " SECOND_BAL ", 0\n\t"                                                                                       \
     "s_cbranch_scc1 5f\n"                                                                                                \
     "4:\n\t" /* pop */                                                                                                   \
     "v_readfirstlane_b32 %[cur], %[tos]\n\t"                                                                             \
@@ -415,7 +413,6 @@ __device__ __forceinline__ void packet_triangle_asm(const void *tri_base, uint32
     "s_load_dwordx4 s[56:59], %[tb], s62 offset:0x20\n"                                                                  \
     "8:\n\t"                                                                                                             \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
-    "s_nop 0\n\t"                                                                                                        \
     "v_pk_mul_f32 v[48:49], %[pz], s[58:59] op_sel_hi:[1,0]\n\t"                                                         \
     "v_pk_fma_f32 v[48:49], %[py], s[56:57], v[48:49] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                              \
     "v_pk_fma_f32 v[48:49], %[px], s[56:57], v[48:49] op_sel_hi:[1,0,1]\n\t"                                             \
@@ -502,11 +499,11 @@ __device__ __forceinline__ int32_t packet_blas_asm(const RtSceneView &S, FastTra
 #define RT_BLAS_CASE(N, X, Y, Z)                                                                                   \
     if constexpr (OCT == N) {                                                                                      \
         if constexpr (ANYHIT && !RT_ANYHIT_ORDERED)                                                                \
-            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_WALK_LEFT_FIRST, RT_BLAS_TAKE_ANY, RT_BLAS_LEAF_END_ANY));         \
+            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_ORDER_LEFT, RT_BLAS_TAKE_ANY, RT_BLAS_LEAF_END_ANY));         \
         else if constexpr (ANYHIT)                                                                                 \
-            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_WALK_ORDERED(#N), RT_BLAS_TAKE_ANY, RT_BLAS_LEAF_END_ANY));        \
+            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_ORDER_OCT(#N), RT_BLAS_TAKE_ANY, RT_BLAS_LEAF_END_ANY));        \
         else                                                                                                       \
-            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_WALK_ORDERED(#N), RT_BLAS_TAKE_CLOSEST, RT_BLAS_LEAF_END_CLOSEST)); \
+            RT_BLAS_RUN(RT_BLAS_ASM(X, Y, Z, RT_ORDER_OCT(#N), RT_BLAS_TAKE_CLOSEST, RT_BLAS_LEAF_END_CLOSEST)); \
     }
     RT_BLAS_CASE(0, RT_WALK_X_POS, RT_WALK_Y_POS, RT_WALK_Z_POS)
     RT_BLAS_CASE(1, RT_WALK_X_NEG, RT_WALK_Y_POS, RT_WALK_Z_POS)
