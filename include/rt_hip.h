@@ -185,8 +185,10 @@ typedef struct RtRenderArgs {
 enum {
     RT_RENDER_NO_PACKETS = 1,       /* RT_MODE_FAST: one ray per lane for camera and shadow rays too */
     RT_RENDER_ROW_MAJOR_PIXELS = 2, /* work the pixels of a tile row by row instead of in small blocks */
-    RT_RENDER_UNFUSED_SHADOWS = 4   /* RT_MODE_FAST: one shadow-ray launch per light and a separate launch for the
+    RT_RENDER_UNFUSED_SHADOWS = 4,  /* RT_MODE_FAST: one shadow-ray launch per light and a separate launch for the
                                        light sums, instead of one kernel for both */
+    RT_RENDER_UNFUSED_CAMERA = 8    /* RT_MODE_FAST: the camera rays and the stage that decides what happens to their
+                                       hits as two launches (the hit records go through memory), instead of one */
 };
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is

@@ -245,11 +245,11 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
             *Q.overflow = 1;
             return;
         }
-        // As a batch's first kernel (camera rays) it also zeroes the batch's counters and per-chunk lit counts,
-        // which the stages behind it add to: a store by the first few waves instead of a memset (two more
-        // launches in front of every frame).  n_clear = 0: the caller has cleared them.
+        // As a batch's first kernel (camera rays) it also zeroes the counters and per-chunk lit counts that the
+        // NEXT batch is going to add to (the set this batch does not use): a store by the first few waves
+        // instead of a memset (two more launches in front of every frame).  n_clear = 0: nothing to clear.
         if (KIND == 0)
-            for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < K.n_clear; i += gridDim.x * RT_PACKET_BLOCK) K.Q.counters[i] = 0u;
+            for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < K.n_clear; i += gridDim.x * RT_PACKET_BLOCK) K.Q.counters_next[i] = 0u;
         count = KIND == 1 ? K.Q.counters[RT_CNT_LIT] : K.n_samples;
         const uint32_t n_blocks = (count + per_block - 1) / per_block;  // blocks that have work; the rest leave
         if (blockIdx.x >= n_blocks) return;
@@ -393,6 +393,71 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         const uint32_t sample = K.Q.lit_list[idx];
         accumulate_masked<true>(K.S, K.Q, sample, RT_STREAM_LD(K.Q.l_shape[sample]), *hidden_slot);  // fast mode only
     }
+}
+
+// Camera rays AND the stage behind them in one kernel (fast mode): the wave walks the tree with its 64 camera
+// rays as a packet and then decides what happens to each hit (k_shade<true>'s work) without the hit records
+// going through memory.  Like k_trace_packet<0> it zeroes the next batch's counters (its own are being
+// added to by its waves).
+#ifndef RT_CAMERA_WAVES
+#define RT_CAMERA_WAVES 7
+#endif
+struct CameraKernargs {
+    RtSceneView S;
+    RtBuffers Q;
+    RtBatch B;
+    RtIdOut ids;
+    uint32_t n_samples, xcd_chunk, n_clear;
+};
+typedef const __attribute__((address_space(4))) CameraKernargs *CameraKernargsPtr;
+
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_CAMERA_WAVES, RT_CAMERA_WAVES)))
+k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples, uint32_t xcd_chunk, uint32_t n_clear) {
+    extern __shared__ int32_t lds[];
+    const CameraKernargsPtr args = (CameraKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t count, idx0;
+    int rows;
+    {
+        const CameraKernargs &K = fresh(args);
+        if (K.Q.lit_list != Q.lit_list || K.n_clear != n_clear) {  // the layout assumed for the argument segment
+            *Q.overflow = 1;
+            return;
+        }
+        for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < K.n_clear; i += gridDim.x * RT_PACKET_BLOCK) K.Q.counters_next[i] = 0u;
+        count = K.n_samples;
+        const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+        if (blockIdx.x >= n_blocks) return;
+        idx0 = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+        rows = K.S.stack_depth + 1;
+    }
+    FastTrav st[1];
+    {
+        const CameraKernargs &K = fresh(args);
+        RaySetup r;
+        if (!(idx0 < count && closest_setup(K.S, K.Q, K.B, 0, idx0, r))) {  // a slot without a ray: finite dummy values and an empty search interval
+            r.o = D3{0.0, 0.0, 0.0};
+            r.d = D3{0.0, 0.0, -1.0};
+            r.t0 = -__builtin_inff();
+            r.shape0 = -1;
+            r.org_shape = r.org_tri = -1;
+        }
+        fast_set_ray(st[0], (float)r.o.x, (float)r.o.y, (float)r.o.z, (float)r.d.x, (float)r.d.y, (float)r.d.z);
+        st[0].t = r.t0;
+        st[0].shape = r.shape0;
+        st[0].tri = -1;
+        st[0].org_shape = r.org_shape;
+        st[0].org_tri = r.org_tri;
+    }
+    const bool ok = packet_traverse<false, 1>(S, st, closest_tmin(0), lds, rows - 1);  // (the walk's fields of S stay in registers)
+    const CameraKernargs &K = fresh(args);
+    if (!ok) *K.Q.overflow = 1;
+    const uint32_t idx = opaque(idx0);
+    MirrorTmp tmp;
+    const int act = idx < count ? shade_hit(K.S, K.Q, K.B, K.ids, 0, idx, st[0].shape, st[0].tri, st[0].t, tmp) : RT_ACT_NONE;
+    const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, &K.Q.counters[RT_CNT_RAYS0 + 1]);
+    if (act == RT_ACT_MIRROR) shade_commit_mirror(K.Q, 0, slot, tmp);
+    const unsigned long long lit = __ballot(act == RT_ACT_LIT);
+    if (lit != 0ull && threadIdx.x == 0u) atomicAdd(&K.Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(lit));
 }
 
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
@@ -723,11 +788,13 @@ bool assign_buffers(RtBuffers &Q, uint32_t capacity, uint32_t n_point_lights, Ta
     get(&Q.occ_tri, cap * npl);
     get(&Q.occ_t, cap * npl);
     get(&Q.color, cap * 3);
-    // the counters and, behind them, the per-chunk lit counts: one memset clears both
-    get(&Q.counters, (size_t)RT_CNT_SIZE + cap / RT_LIT_CHUNK + 1);
+    // the counters and, behind them, the per-chunk lit counts (one memset clears both), twice: see counters_next
+    const size_t set_words = ((size_t)RT_CNT_SIZE + cap / RT_LIT_CHUNK + 1 + 63u) & ~(size_t)63u;
+    get(&Q.counters, 2 * set_words);
     get(&Q.lit_list, cap);
     if (!ok) return false;
     Q.block_counts = Q.counters + RT_CNT_SIZE;
+    Q.counters_next = Q.counters + set_words;
     Q.capacity = capacity;
     return true;
 }
@@ -760,6 +827,7 @@ int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
         return rt::set_error(RT_ERR_DEVICE, std::string("hipMalloc of the batch buffers: ") + hipGetErrorString(err));
     }
     be->buf.overflow = be->sticky;
+    be->counter_dirty[0] = be->counter_dirty[1] = ~0u;  // fresh memory: nothing is known to be zero
     be->buf_capacity = capacity;
     be->buf_point_lights = n_point_lights;
     return RT_OK;
@@ -995,6 +1063,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     const bool use_packets = (args->flags & RT_RENDER_NO_PACKETS) == 0u;
     // shadow rays and light sums in one kernel: needs the packet path and a bit per point light
     const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u;
+    // camera rays and the stage behind them in one kernel: needs the packet path
+    const bool fuse_camera = !ref_order && use_packets && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
     // One ray per lane in the packet kernels.  Two per lane (the template's R) halve the steps per
     // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
@@ -1024,11 +1094,34 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         const uint32_t n_samples = B.n_pixels * spp;
 
         const uint32_t lit_grid = (n_samples + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
-        // counters and per-chunk lit counts start at zero: cleared by the camera-ray packet kernel where that
-        // is the batch's first kernel, by a memset otherwise
+        // Counters and per-chunk lit counts start at zero.  A backend's batches take turns with two sets of
+        // them: where the batch's first kernel is a camera-ray packet kernel, that kernel zeroes the set the
+        // previous batch used (for the next one), so that no memset stands in front of a frame; any other batch
+        // clears its own set with a memset.  (The static work array is shared by all backends of a device, so
+        // nothing is known about its sets from one call to the next: always a memset.)
         const uint32_t n_counters = (uint32_t)RT_CNT_SIZE + lit_grid;
-        const bool clear_in_kernel = !ds->has_ggx && !ref_order && use_packets;
-        if (!clear_in_kernel) RT_HIP(hipMemsetAsync(Q.counters, 0, (size_t)n_counters * sizeof(uint32_t), stream));
+        const bool clear_in_kernel = !ds->has_ggx && !ref_order && use_packets && !static_memory;
+        uint32_t n_clear = 0;
+        {
+            uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
+                                       Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
+            const uint32_t set_words = (uint32_t)(sets[1] - sets[0]);
+            uint32_t dirty_static[2] = {~0u, ~0u};
+            uint32_t *dirty = static_memory ? dirty_static : be->counter_dirty;
+            // a clean set if there is one and this batch keeps the turns going, else a dirty one (and the memset)
+            int use = 0;
+            if (clear_in_kernel) use = dirty[0] == 0u ? 0 : dirty[1] == 0u ? 1 : 0;
+            else use = dirty[0] == 0u && dirty[1] != 0u ? 1 : 0;
+            if (dirty[use] != 0u) RT_HIP(hipMemsetAsync(sets[use], 0, (size_t)n_counters * sizeof(uint32_t), stream));
+            dirty[use] = std::max(dirty[use], n_counters);
+            if (clear_in_kernel) {
+                n_clear = std::min(dirty[use ^ 1], set_words);
+                dirty[use ^ 1] = 0u;
+            }
+            Q.counters = sets[use];
+            Q.block_counts = Q.counters + RT_CNT_SIZE;
+            Q.counters_next = sets[use ^ 1];
+        }
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
@@ -1051,13 +1144,16 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
+            else if (bounce == 0 && fuse_camera)
+                hipLaunchKernelGGL(k_camera_shade_packet, dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, n_samples, xcd_chunk, n_clear);
             else if (bounce == 0 && use_packets)
-                hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, bounce == 0 && clear_in_kernel ? n_counters : 0u);
+                hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, n_clear);
             else
                 hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
             if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            if (bounce == 0)
+            if (bounce == 0 && fuse_camera) {  // done by the camera-ray kernel
+            } else if (bounce == 0)
                 hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, 0, n_samples);
             else
                 hipLaunchKernelGGL((k_shade<false>), dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
@@ -1122,7 +1218,10 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             }
         }
     }
-    RT_HIP(hipGetLastError());
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {  // a launch failed: which counters were zeroed is not known
+        be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
+        return rt::set_error(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    }
     if (!stats && !tm.pairs.empty()) {  // read later by rt_collect_timings
         be->deferred.insert(be->deferred.end(), tm.pairs.begin(), tm.pairs.end());
         be->deferred_stream = stream;

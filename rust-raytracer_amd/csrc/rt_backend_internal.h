@@ -36,6 +36,8 @@ struct RtBackend {
     std::vector<void *> buf_allocs;
     uint32_t buf_capacity = 0;
     uint32_t buf_point_lights = 0;
+    // leading words of each of buf's two counter sets that may be non-zero (0: the set is clean, ~0u: all of it)
+    uint32_t counter_dirty[2] = {~0u, ~0u};
     // "a traversal stack overflowed" (RtBuffers::overflow): a device word that kernels only ever set,
     // and the page-locked host word it is copied to when the host looks
     uint32_t *sticky = nullptr;

@@ -72,6 +72,8 @@ struct RtBuffers {
                              // cleared by the device, so that it survives until the host looks
     uint32_t *block_counts;  // lit hits per chunk of RT_LIT_CHUNK samples (added up by the shade stage), then
                              // their exclusive prefix sums; lies behind the counters and is cleared with them
+    uint32_t *counters_next; // the other of the two sets of counters and chunk counts: batches take turns with them,
+                             // and a batch's first kernel zeroes the set of the batch behind it where it can
     uint32_t *lit_list;      // samples that have a lit hit, ascending
     uint32_t capacity;       // samples a batch can hold
     uint32_t lit_f32;        // set per frame: the lit table's vectors are stored as f32 (fast mode), see lit_store_vec
@@ -296,13 +298,11 @@ RT_HD void write_color(const RtBuffers &Q, int32_t sample, float r, float g, flo
 // no further ray are written here; a lit hit goes into the sample's slot of the lit
 // table together with the origin primitive's own shadow test; a mirror ray is
 // returned for the caller to append to the next queue.
-RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, int bounce,
-                         uint32_t idx, MirrorTmp &tmp) {
+// (shape, gtri, hit_t) is the ray's hit record as the trace stage leaves it.
+RT_HD int shade_hit(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, int bounce,
+                    uint32_t idx, int32_t shape, int32_t gtri, float hit_t, MirrorTmp &tmp) {
     D3 o, d;
     int32_t sample;
-    // the hit record first: its loads are then in flight while the camera ray is computed again
-    const int32_t shape = RT_STREAM_LD(Q.h_shape[idx]), gtri = RT_STREAM_LD(Q.h_tri[idx]);
-    const float hit_t = RT_STREAM_LD(Q.h_t[idx]);
     if (bounce == 0) {
         sample = (int32_t)idx;
         Q.l_shape[sample] = -1;  // every sample passes here exactly once: this clears the lit table
@@ -390,6 +390,15 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
         write_color(Q, sample, 1.0f, 0.0f, 1.0f);
         return RT_ACT_NONE;
     }
+}
+
+// The same for a hit record that lies in the batch's hit arrays.
+RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, int bounce,
+                         uint32_t idx, MirrorTmp &tmp) {
+    // the hit record first: its loads are then in flight while the camera ray is computed again
+    const int32_t shape = RT_STREAM_LD(Q.h_shape[idx]), gtri = RT_STREAM_LD(Q.h_tri[idx]);
+    const float hit_t = RT_STREAM_LD(Q.h_t[idx]);
+    return shade_hit(S, Q, B, ids, bounce, idx, shape, gtri, hit_t, tmp);
 }
 
 RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const MirrorTmp &tmp) {

@@ -278,18 +278,28 @@ def test_async_render_into_pinned_memory(rt, backend, scene_path):
 
 
 def test_fused_and_separate_shadow_kernels_agree(rt, backend, scene_path):
-    """Fast mode traces the shadow rays and sums the lights in one kernel; RT_RENDER_UNFUSED_SHADOWS keeps
-    one launch per light and a separate accumulate launch, RT_RENDER_NO_PACKETS the per-lane kernels,
-    RT_RENDER_ROW_MAJOR_PIXELS the plain pixel order.  None of them may change a pixel or a count."""
+    """Fast mode traces the shadow rays and sums the lights in one kernel, and the camera rays and the stage
+    behind them in another; RT_RENDER_UNFUSED_SHADOWS keeps one launch per light and a separate accumulate
+    launch, RT_RENDER_UNFUSED_CAMERA a launch for the camera rays and one for their hits,
+    RT_RENDER_NO_PACKETS the per-lane kernels, RT_RENDER_ROW_MAJOR_PIXELS the plain pixel order.  None of
+    them may change a pixel or a count."""
     for name in ("mixed_features", "bunny_small", "spheres_1K"):
         scene = rt.parse_scene_file(scene_path(name), image_width=200, image_height=150, recursion_depth=6)
         dev = backend.upload(scene)
         base, ids0, st0 = dev.render(3, want_ids=True)
-        for flags in (rt.RT_RENDER_UNFUSED_SHADOWS, rt.RT_RENDER_NO_PACKETS, rt.RT_RENDER_ROW_MAJOR_PIXELS):
+        for flags in (rt.RT_RENDER_UNFUSED_SHADOWS, rt.RT_RENDER_UNFUSED_CAMERA, rt.RT_RENDER_UNFUSED_CAMERA | rt.RT_RENDER_UNFUSED_SHADOWS,
+                      rt.RT_RENDER_NO_PACKETS, rt.RT_RENDER_ROW_MAJOR_PIXELS):
             fb, ids, st = dev.render(3, want_ids=True, flags=flags)
             assert np.array_equal(fb.pixels, base.pixels), (name, flags)
             assert np.array_equal(ids.shadow_shape >= 0, ids0.shadow_shape >= 0) and np.array_equal(ids.shadow_shape == -2, ids0.shadow_shape == -2)
             assert np.array_equal(ids.primary_tri, ids0.primary_tri) and st.total_rays() == st0.total_rays()
+            for field in ("primary_shape", "final_shape", "final_tri", "bounces"):
+                assert np.array_equal(getattr(ids, field), getattr(ids0, field)), (name, flags, field)
+        # frames that clear their counters in different ways, back to back on one backend and without
+        # statistics (nothing waits between them): every one must still see zeroed counters
+        for flags in (0, rt.RT_RENDER_NO_PACKETS, 0, 0, rt.RT_RENDER_UNFUSED_CAMERA, rt.RT_RENDER_NO_PACKETS, rt.RT_RENDER_NO_PACKETS, 0):
+            fb, _, _ = dev.render(3, flags=flags, want_stats=False)
+            assert np.array_equal(fb.pixels, base.pixels), (name, flags)
         dev.close()
     scene = rt.parse_scene_file(scene_path("bunny_small"), image_width=200, image_height=150, recursion_depth=6)
     a = backend.upload(scene)
