@@ -430,30 +430,50 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         idx0 = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
         rows = K.S.stack_depth + 1;
     }
+    // The sample's point on the image plane waits in LDS behind the walk's rows, a column of four words per
+    // lane: the ray is needed again for the hit point, and the plane point is the expensive part of it
+    // (index arithmetic and four f64 divisions) while the walk has no register to spare for it.
+    int32_t *plane = lds + rt_packet_lds_dwords(rows) + threadIdx.x;
     FastTrav st[1];
+    bool live;
     {
         const CameraKernargs &K = fresh(args);
         RaySetup r;
-        if (!(idx0 < count && closest_setup(K.S, K.Q, K.B, 0, idx0, r))) {  // a slot without a ray: finite dummy values and an empty search interval
+        double u = 0.0, v = 0.0;
+        live = idx0 < count && sample_plane_point(K.S, K.B, idx0, u, v);
+        if (live) {
+            camera_ray_through(K.S.camera, u, v, r.o, r.d);
+            r.t0 = __builtin_inff();
+        } else {  // a slot without a ray: finite dummy values and an empty search interval
             r.o = D3{0.0, 0.0, 0.0};
             r.d = D3{0.0, 0.0, -1.0};
             r.t0 = -__builtin_inff();
-            r.shape0 = -1;
-            r.org_shape = r.org_tri = -1;
         }
+        plane[0 * RT_PACKET_BLOCK] = __double2loint(u);
+        plane[1 * RT_PACKET_BLOCK] = __double2hiint(u);
+        plane[2 * RT_PACKET_BLOCK] = __double2loint(v);
+        plane[3 * RT_PACKET_BLOCK] = __double2hiint(v);
         fast_set_ray(st[0], (float)r.o.x, (float)r.o.y, (float)r.o.z, (float)r.d.x, (float)r.d.y, (float)r.d.z);
         st[0].t = r.t0;
-        st[0].shape = r.shape0;
+        st[0].shape = -1;
         st[0].tri = -1;
-        st[0].org_shape = r.org_shape;
-        st[0].org_tri = r.org_tri;
+        st[0].org_shape = -1;
+        st[0].org_tri = -1;
     }
     const bool ok = packet_traverse<false, 1>(S, st, closest_tmin(0), lds, rows - 1);  // (the walk's fields of S stay in registers)
     const CameraKernargs &K = fresh(args);
     if (!ok) *K.Q.overflow = 1;
     const uint32_t idx = opaque(idx0);
     MirrorTmp tmp;
-    const int act = idx < count ? shade_hit(K.S, K.Q, K.B, K.ids, 0, idx, st[0].shape, st[0].tri, st[0].t, tmp) : RT_ACT_NONE;
+    int act = RT_ACT_NONE;
+    if (live) {
+        D3 o, d;
+        camera_ray_through(K.S.camera, __hiloint2double(plane[1 * RT_PACKET_BLOCK], plane[0 * RT_PACKET_BLOCK]),
+                           __hiloint2double(plane[3 * RT_PACKET_BLOCK], plane[2 * RT_PACKET_BLOCK]), o, d);
+        act = shade_hit(K.S, K.Q, K.B, K.ids, 0, (int32_t)idx, o, d, st[0].shape, st[0].tri, st[0].t, tmp);
+    }
+    // every sample of the batch passes here exactly once: this clears the lit table where no lit hit was stored
+    if (idx < count && act != RT_ACT_LIT) K.Q.l_shape[idx] = -1;
     const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, &K.Q.counters[RT_CNT_RAYS0 + 1]);
     if (act == RT_ACT_MIRROR) shade_commit_mirror(K.Q, 0, slot, tmp);
     const unsigned long long lit = __ballot(act == RT_ACT_LIT);
@@ -1071,6 +1091,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     constexpr int packet_rays = 1;
     // stack rows, the world-space rays of a wave inside an instance, and (fused kernel) a word per lane
     const size_t packet_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 64u) * sizeof(int32_t);  // + the fused kernel's word per lane
+    const size_t camera_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 4u * 64u) * sizeof(int32_t);  // + the plane point
     // a wait per batch: to read the counters for the statistics, or to serve the progress callback
     const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
     const bool wait_batches = stats != nullptr || serve_progress;
@@ -1145,15 +1166,15 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             else if (bounce == 0 && fuse_camera)
-                hipLaunchKernelGGL(k_camera_shade_packet, dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, n_samples, xcd_chunk, n_clear);
+                hipLaunchKernelGGL(k_camera_shade_packet, dim3(packet_grid), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, Q, B, io, n_samples, xcd_chunk, n_clear);
             else if (bounce == 0 && use_packets)
                 hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, n_clear);
             else
                 hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
             tm.end();
+            if (bounce == 0 && fuse_camera) continue;  // the camera-ray kernel has done the stage behind it too
             if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            if (bounce == 0 && fuse_camera) {  // done by the camera-ray kernel
-            } else if (bounce == 0)
+            if (bounce == 0)
                 hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, 0, n_samples);
             else
                 hipLaunchKernelGGL((k_shade<false>), dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);

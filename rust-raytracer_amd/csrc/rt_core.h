@@ -979,10 +979,13 @@ RT_HD void sample_offsets(int32_t method, uint64_t seed, uint64_t sample, uint32
     }
 }
 
-// camera/mod.rs:52-56 + perspective.rs:20-28 / orthographic.rs:19-26
-RT_HD void camera_ray(const RtCamera &cam, uint32_t i, uint32_t j, double di, double dj, D3 &o, D3 &d) {
-    const double u = cam.left + (cam.right - cam.left) * ((double)i + di) / (double)cam.pixels_x;
-    const double v = cam.bottom + (cam.top - cam.bottom) * ((double)j + dj) / (double)cam.pixels_y;
+// camera/mod.rs:52-56 + perspective.rs:20-28 / orthographic.rs:19-26, in two steps: the sample's point
+// (u, v) on the image plane, and the ray through it.
+RT_HD void camera_plane_point(const RtCamera &cam, uint32_t i, uint32_t j, double di, double dj, double &u, double &v) {
+    u = cam.left + (cam.right - cam.left) * ((double)i + di) / (double)cam.pixels_x;
+    v = cam.bottom + (cam.top - cam.bottom) * ((double)j + dj) / (double)cam.pixels_y;
+}
+RT_HD void camera_ray_through(const RtCamera &cam, double u, double v, D3 &o, D3 &d) {
     if (cam.type == RT_CAMERA_PERSPECTIVE) {
         o = d3(cam.position);
         d = (d3(cam.u) * u + d3(cam.v) * v) - d3(cam.w) * cam.focal_length;
@@ -990,6 +993,11 @@ RT_HD void camera_ray(const RtCamera &cam, uint32_t i, uint32_t j, double di, do
         o = d3(cam.position) + D3{u, v, 0.0};
         d = D3{0.0, 0.0, -1.0};
     }
+}
+RT_HD void camera_ray(const RtCamera &cam, uint32_t i, uint32_t j, double di, double dj, D3 &o, D3 &d) {
+    double u, v;
+    camera_plane_point(cam, i, j, di, dj, u, v);
+    camera_ray_through(cam, u, v, o, d);
 }
 
 // ---------------------------------------------------------------- shading

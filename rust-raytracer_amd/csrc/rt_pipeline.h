@@ -161,7 +161,7 @@ RT_HD int32_t tri_file_index(const RtSceneView &S, int32_t gtri) {
 
 // Camera ray of a local sample (render.rs:64-68); false for the padding pixels of
 // a tile that sticks out of the image.
-RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls, D3 &o, D3 &d) {
+RT_HD bool sample_plane_point(const RtSceneView &S, const RtBatch &B, uint32_t ls, double &u, double &v) {
     const uint32_t spp = B.div_spp.d;
     const uint32_t lp = rt_div(ls, B.div_spp);
     uint32_t i, j;
@@ -170,7 +170,13 @@ RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls
     const uint32_t p = rt_div(k, B.div_n);
     double di, dj;
     sample_offsets(B.aa_method, B.seed, ((uint64_t)i + (uint64_t)j * B.width) * spp + k, p, k - p * B.n, B.n, di, dj);
-    camera_ray(S.camera, i, j, di, dj, o, d);
+    camera_plane_point(S.camera, i, j, di, dj, u, v);
+    return true;
+}
+RT_HD bool sample_camera_ray(const RtSceneView &S, const RtBatch &B, uint32_t ls, D3 &o, D3 &d) {
+    double u, v;
+    if (!sample_plane_point(S, B, ls, u, v)) return false;
+    camera_ray_through(S.camera, u, v, o, d);
     return true;
 }
 
@@ -298,20 +304,9 @@ RT_HD void write_color(const RtBuffers &Q, int32_t sample, float r, float g, flo
 // no further ray are written here; a lit hit goes into the sample's slot of the lit
 // table together with the origin primitive's own shadow test; a mirror ray is
 // returned for the caller to append to the next queue.
-// (shape, gtri, hit_t) is the ray's hit record as the trace stage leaves it.
+// (o, d) is the traced ray of `sample` and (shape, gtri, hit_t) its hit record as the trace stage leaves it.
 RT_HD int shade_hit(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, int bounce,
-                    uint32_t idx, int32_t shape, int32_t gtri, float hit_t, MirrorTmp &tmp) {
-    D3 o, d;
-    int32_t sample;
-    if (bounce == 0) {
-        sample = (int32_t)idx;
-        Q.l_shape[sample] = -1;  // every sample passes here exactly once: this clears the lit table
-        if (!sample_camera_ray(S, B, idx, o, d)) return RT_ACT_NONE;
-    } else {
-        const int which = bounce & 1;
-        sample = Q.q_sample[which][idx];
-        queue_read_ray(Q, which, idx, o, d);
-    }
+                    int32_t sample, const D3 &o, const D3 &d, int32_t shape, int32_t gtri, float hit_t, MirrorTmp &tmp) {
     const bool want_ids = ids.primary_shape || ids.primary_tri || ids.final_shape || ids.final_tri || ids.bounces;
     const size_t gs = want_ids ? global_sample(B, (uint32_t)sample) : 0;
     const int32_t ftri = tri_file_index(S, gtri);
@@ -392,13 +387,24 @@ RT_HD int shade_hit(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, 
     }
 }
 
-// The same for a hit record that lies in the batch's hit arrays.
+// The same for a hit record that lies in the batch's hit arrays, the ray computed (bounce 0) or read again.
 RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, int bounce,
                          uint32_t idx, MirrorTmp &tmp) {
     // the hit record first: its loads are then in flight while the camera ray is computed again
     const int32_t shape = RT_STREAM_LD(Q.h_shape[idx]), gtri = RT_STREAM_LD(Q.h_tri[idx]);
     const float hit_t = RT_STREAM_LD(Q.h_t[idx]);
-    return shade_hit(S, Q, B, ids, bounce, idx, shape, gtri, hit_t, tmp);
+    D3 o, d;
+    int32_t sample;
+    if (bounce == 0) {
+        sample = (int32_t)idx;
+        Q.l_shape[sample] = -1;  // every sample passes here exactly once: this clears the lit table
+        if (!sample_camera_ray(S, B, idx, o, d)) return RT_ACT_NONE;
+    } else {
+        const int which = bounce & 1;
+        sample = Q.q_sample[which][idx];
+        queue_read_ray(Q, which, idx, o, d);
+    }
+    return shade_hit(S, Q, B, ids, bounce, sample, o, d, shape, gtri, hit_t, tmp);
 }
 
 RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const MirrorTmp &tmp) {
