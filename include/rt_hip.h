@@ -188,7 +188,8 @@ enum {
     RT_RENDER_UNFUSED_SHADOWS = 4,  /* RT_MODE_FAST: one shadow-ray launch per light and a separate launch for the
                                        light sums, instead of one kernel for both */
     RT_RENDER_UNFUSED_CAMERA = 8    /* RT_MODE_FAST: the camera rays and the stage that decides what happens to their
-                                       hits as two launches (the hit records go through memory), instead of one */
+                                       hits as two launches (the hit records go through memory) instead of one, and
+                                       likewise two launches per mirror bounce instead of one for all bounces */
 };
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is

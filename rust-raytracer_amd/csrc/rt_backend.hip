@@ -480,6 +480,106 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     if (lit != 0ull && threadIdx.x == 0u) atomicAdd(&K.Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(lit));
 }
 
+// ALL mirror bounces in one kernel (fast mode): a lane takes a ray from the first bounce's queue, follows it
+// to its hit, decides what happens there (the stage behind the rays; the hit record stays in registers), and
+// where the hit is another mirror it goes on with the reflected ray itself.  A ray's way through one bounce
+// is a chain of dependent memory round trips and f64 arithmetic some 25 us long, so a launch per bounce and
+// one more for the stage behind it took that long each however few rays were left, with the GPU drained in
+// between (cornell_room, six bounces: 0.14 ms for the first, 0.13 ms for the five behind it, whose rays are
+// a tenth of the first's).  One launch takes as long as those did together (0.265 ms) but leaves no gaps
+// for a frame in flight beside it: cornell_room 0.785 -> 0.757 ms per delivered frame.  Lanes whose ray has
+// ended idle until the wave's last one has: against compacting the rays after every bounce that costs
+// nothing measurable even where mirrors dominate (the same room with floor and back wall mirrors, 6.5 M
+// mirror rays: 2.35 vs 2.37 ms; every wall a mirror, 27.7 M: 7.0 vs 7.3 ms).
+// The reflected ray goes through the lane's own queue slot, so that a round of the loop starts from memory
+// like the first one and nothing but the slot's index lives across it.  The rounds of a wave are in step
+// (round k is bounce k + 1 for every lane that is still going), so the counts of rays per bounce that the
+// statistics report are kept with one add per wave and round.
+// Only the device knows how long the queue is, so the grid is small and its blocks stride over the queue.
+// The arguments are read again in every round (`fresh`), so that the compiler does not keep the address of
+// every queue and table in registers across the loops.
+#ifndef RT_BOUNCE_WAVES
+#define RT_BOUNCE_WAVES 6
+#endif
+// as many blocks as are resident at once, 256 CUs x (4 SIMDs x RT_BOUNCE_WAVES waves / 4 waves per block):
+// cornell_room 1.036 / 1.018 / 1.045 / 1.088 ms per instrumented frame with 1024 / 1536 / 2048 / 4096 blocks,
+// the same room with every wall a mirror (27.7 M mirror rays) 7.11 / 7.00 / 7.35 / 7.21
+#define RT_BOUNCE_GRID (256u * RT_BOUNCE_WAVES)
+struct BounceKernargs {
+    RtSceneView S;
+    RtBuffers Q;
+    RtBatch B;
+    RtIdOut ids;
+    uint32_t xcd_chunk;
+};
+typedef const __attribute__((address_space(4))) BounceKernargs *BounceKernargsPtr;
+
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_WAVES, RT_BOUNCE_WAVES)))
+k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
+    extern __shared__ int32_t lds[];
+    const BounceKernargsPtr args = (BounceKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    {
+        const BounceKernargs &K = fresh(args);
+        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != xcd_chunk) {  // the layout assumed for the argument segment
+            *Q.overflow = 1;
+            return;
+        }
+    }
+    constexpr int which = 1;  // the queue of bounce 1
+    const uint32_t count = Q.counters[RT_CNT_RAYS0 + 1];
+    const uint32_t n_blocks = (count + RT_BLOCK - 1) / RT_BLOCK;
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t idx = xcd_chunked_block(blk, n_blocks, fresh(args).xcd_chunk) * RT_BLOCK + threadIdx.x;
+        bool going = idx < count;
+        for (int b = 1; __any(going); ++b) {
+            const BounceKernargs &K = fresh(args);
+            LdsStack stk{lds + threadIdx.x, K.S.stack_depth};
+            FastTrav st;
+            st.t = __builtin_inff();
+            st.shape = st.tri = -1;
+            if (going) {
+                {
+                    D3 o, d;
+                    queue_read_ray(K.Q, which, idx, o, d);
+                    const int32_t org_shape = K.Q.q_org_shape[which][idx];
+                    const float self_t = K.Q.q_self_t[which][idx];
+                    const bool self = self_t < __builtin_inff();  // the origin primitive's own re-hit
+                    fast_begin(K.S, st, stk, o, d, self ? self_t : __builtin_inff(), self ? org_shape : -1, org_shape, K.Q.q_org_tri[which][idx]);
+                }
+                bool overflow = false;
+                const float tmin = closest_tmin(1);
+                while (fast_step<LdsStack, false>(K.S, st, stk, tmin, K.S.stack_depth, overflow)) {
+                }
+                if (overflow) *K.Q.overflow = 1;
+            }
+            const BounceKernargs &L = fresh(args);
+            MirrorTmp tmp;
+            int act = RT_ACT_NONE;
+            int32_t sample = 0;
+            if (going) {
+                D3 o, d;
+                sample = L.Q.q_sample[which][idx];
+                queue_read_ray(L.Q, which, idx, o, d);
+                act = shade_hit(L.S, L.Q, L.B, L.ids, b, sample, o, d, st.shape, st.tri, st.t, tmp);
+            }
+            going = act == RT_ACT_MIRROR;
+            if (going) queue_write_ray(L.Q, which, idx, tmp);
+            const unsigned long long on = __ballot(going);
+            if (on != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&L.Q.counters[RT_CNT_RAYS0 + b + 1], (uint32_t)__popcll(on));
+            // lit hits per chunk of samples, one add per distinct chunk among the wave's lit lanes (as k_shade does)
+            unsigned long long todo = __ballot(act == RT_ACT_LIT);
+            const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)sample / RT_LIT_CHUNK : ~0u;
+            while (todo != 0ull) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t of = (uint32_t)__shfl((int)chunk, leader, 64);
+                const unsigned long long same = __ballot(chunk == of);
+                if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&L.Q.block_counts[of], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+}
+
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
 // The traversal stack lives in LDS like the per-lane kernels'; the tree's own stack of waiting
 // GGX hits is per-thread scratch memory.
@@ -1085,6 +1185,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u;
     // camera rays and the stage behind them in one kernel: needs the packet path
     const bool fuse_camera = !ref_order && use_packets && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
+    // a mirror bounce (its rays and the stage behind them) in one kernel
+    const bool fuse_bounce = !ref_order && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
     // One ray per lane in the packet kernels.  Two per lane (the template's R) halve the steps per
     // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
@@ -1162,6 +1264,13 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
             // the device, so a fixed grid strides over it (and costs little when it is empty).
             const uint32_t g = bounce == 0 ? full_grid : std::min<uint32_t>(full_grid, RT_MAX_GRID);
+            if (bounce > 0 && fuse_bounce) {  // one launch follows the rays of bounce 1 through all later bounces
+                if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
+                hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);
+                tm.end();
+                break;
+            }
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
                 hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);

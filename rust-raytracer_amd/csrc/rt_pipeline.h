@@ -407,14 +407,17 @@ RT_HD int shade_classify(const RtSceneView &S, const RtBuffers &Q, const RtBatch
     return shade_hit(S, Q, B, ids, bounce, sample, o, d, shape, gtri, hit_t, tmp);
 }
 
-RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const MirrorTmp &tmp) {
-    const int which = (bounce + 1) & 1;
+// Puts a reflected ray into slot `slot` of mirror-ray queue `which`.
+RT_HD void queue_write_ray(const RtBuffers &Q, int which, uint32_t slot, const MirrorTmp &tmp) {
     RT_STREAM_ST(Q.q_o[which][0][slot], tmp.p.x); RT_STREAM_ST(Q.q_o[which][1][slot], tmp.p.y); RT_STREAM_ST(Q.q_o[which][2][slot], tmp.p.z);
     RT_STREAM_ST(Q.q_d[which][0][slot], tmp.d.x); RT_STREAM_ST(Q.q_d[which][1][slot], tmp.d.y); RT_STREAM_ST(Q.q_d[which][2][slot], tmp.d.z);
     RT_STREAM_ST(Q.q_sample[which][slot], tmp.sample);
     RT_STREAM_ST(Q.q_org_shape[which][slot], tmp.shape);
     RT_STREAM_ST(Q.q_org_tri[which][slot], tmp.tri);
     RT_STREAM_ST(Q.q_self_t[which][slot], tmp.self_t);
+}
+RT_HD void shade_commit_mirror(const RtBuffers &Q, int bounce, uint32_t slot, const MirrorTmp &tmp) {
+    queue_write_ray(Q, (bounce + 1) & 1, slot, tmp);
 }
 
 // ---- trace (shadow): light/point.rs:30-37.  Work item = (point light slot, local sample).
