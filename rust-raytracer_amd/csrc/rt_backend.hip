@@ -96,6 +96,28 @@ __device__ __forceinline__ uint32_t wave_alloc(bool pred, uint32_t *counter) {
     return base + rank;
 }
 
+// Lists the wave's lit hits (RtBatch::direct_lit).  `in` = the lanes whose hit is lit and lies in chunk `chunk`
+// (wave-uniform), `entry` = what such a lane lists.  Every lane of the wave must get here.  Counts the hits in
+// block_counts[chunk] in any case; with `list` the count's old value is where the wave's entries go in the
+// chunk's stretch of the lit list.
+// (A list of the packets that hold entries, so that the kernel walking the list would not launch waves for
+// the empty ones, was tried: one more counter, bumped by every wave that starts a packet -- a hundred thousand
+// returning atomics on ONE address, which the memory side serves one at a time, 8 ns each: the camera-ray
+// kernel of the bunny frame took 1.12 ms instead of 0.27.  The per-chunk counters here are a few thousand
+// addresses with sixteen waves each.)
+__device__ __forceinline__ void wave_list_lit(const RtBuffers &Q, bool list, unsigned long long in, bool mine, uint32_t chunk, uint32_t entry) {
+    if (in == 0ull) return;
+    const int leader = __ffsll((long long)in) - 1;
+    uint32_t base = 0u;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&Q.block_counts[chunk], (uint32_t)__popcll(in));
+    if (!list) return;
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (mine) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(in >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in, 0u));
+        Q.lit_list[chunk * RT_LIT_CHUNK + base + rank] = entry;
+    }
+}
+
 // Hardware deals consecutive workgroups round-robin over the 8 XCDs, each with its own
 // 4 MiB L2.  With work items in image order that makes all eight L2s stream the same
 // part of the scene at the same time.  This remap hands XCD x the chunks x, x+8, x+16 ...
@@ -333,10 +355,22 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
             *Q.overflow = 1;
             return;
         }
-        count = K.Q.counters[RT_CNT_LIT];
-        const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
-        if (blockIdx.x >= n_blocks) return;
-        idx0 = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+        if (K.B.direct_lit) {
+            // The lit list has a stretch per chunk of samples, filled from its start (RtBuffers::lit_list): the grid
+            // covers every stretch, and the waves behind a stretch's last entry leave.
+            constexpr uint32_t per_chunk = RT_LIT_CHUNK / RT_PACKET_BLOCK;
+            const uint32_t blk = xcd_chunked_block(blockIdx.x, gridDim.x, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK);
+            const uint32_t chunk = blk / per_chunk, first = (blk % per_chunk) * RT_PACKET_BLOCK;
+            const uint32_t listed = K.Q.block_counts[chunk];
+            if (first >= listed) return;
+            count = chunk * RT_LIT_CHUNK + listed;
+            idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
+        } else {
+            count = K.Q.counters[RT_CNT_LIT];
+            const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
+            if (blockIdx.x >= n_blocks) return;
+            idx0 = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+        }
         rows = K.S.stack_depth + 1;
         n_point_lights = K.S.n_point_lights;
         want_ids = K.ids.shadow_shape != nullptr || K.ids.shadow_tri != nullptr;
@@ -476,8 +510,9 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     if (idx < count && act != RT_ACT_LIT) K.Q.l_shape[idx] = -1;
     const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, &K.Q.counters[RT_CNT_RAYS0 + 1]);
     if (act == RT_ACT_MIRROR) shade_commit_mirror(K.Q, 0, slot, tmp);
-    const unsigned long long lit = __ballot(act == RT_ACT_LIT);
-    if (lit != 0ull && threadIdx.x == 0u) atomicAdd(&K.Q.block_counts[idx / RT_LIT_CHUNK], (uint32_t)__popcll(lit));
+    // Lit hits: counted per chunk of samples (the wave's 64 samples lie in one chunk) and, with direct_lit,
+    // listed at once in the chunk's stretch of the lit list, at the place the count gives.
+    wave_list_lit(K.Q, K.B.direct_lit != 0u, __ballot(act == RT_ACT_LIT), act == RT_ACT_LIT, idx / RT_LIT_CHUNK, idx);
 }
 
 // ALL mirror bounces in one kernel (fast mode): a lane takes a ray from the first bounce's queue, follows it
@@ -573,7 +608,7 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
                 const int leader = __ffsll((long long)todo) - 1;
                 const uint32_t of = (uint32_t)__shfl((int)chunk, leader, 64);
                 const unsigned long long same = __ballot(chunk == of);
-                if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&L.Q.block_counts[of], (uint32_t)__popcll(same));
+                wave_list_lit(L.Q, L.B.direct_lit != 0u, same, chunk == of, of, (uint32_t)sample);
                 todo &= ~same;
             }
         }
@@ -618,6 +653,21 @@ __global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffe
 #define RT_LIT_BLOCK RT_LIT_CHUNK
 #define RT_LIT_THREADS 256
 #define RT_LIT_ROUNDS (RT_LIT_BLOCK / RT_LIT_THREADS)
+
+// One block: counters[RT_CNT_LIT] = sum of block_counts[0..n_blocks), for the statistics of a batch whose lit
+// hits were listed directly (nothing on the device needs the total then).
+__global__ void __launch_bounds__(RT_BLOCK) k_lit_total(RtBuffers Q, uint32_t n_blocks) {
+    __shared__ uint32_t part[RT_BLOCK];
+    uint32_t acc = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += RT_BLOCK) acc += Q.block_counts[b];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t step = RT_BLOCK / 2; step > 0; step /= 2) {
+        if (threadIdx.x < step) part[threadIdx.x] += part[threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Q.counters[RT_CNT_LIT] = part[0];
+}
 
 // One block: block_counts[0..n_blocks) -> exclusive prefix sums in place, total -> counters[RT_CNT_LIT].
 __global__ void __launch_bounds__(RT_LIT_THREADS) k_lit_scan(RtBuffers Q, uint32_t n_blocks) {
@@ -1185,8 +1235,12 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u;
     // camera rays and the stage behind them in one kernel: needs the packet path
     const bool fuse_camera = !ref_order && use_packets && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
-    // a mirror bounce (its rays and the stage behind them) in one kernel
+    // all mirror bounces (their rays and the stage behind them) in one kernel
     const bool fuse_bounce = !ref_order && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
+    // The kernels that find the lit hits list them as they go, each chunk of samples in a stretch of its own, and the
+    // fused shadow kernel takes the stretches as they are: no scan and no scatter launch between them.  (Every other
+    // combination of kernels goes through the compact, ascending list.)
+    const bool direct_lit = fused && fuse_camera && fuse_bounce;
     // One ray per lane in the packet kernels.  Two per lane (the template's R) halve the steps per
     // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
@@ -1209,6 +1263,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         B.n = n;
         B.compact_fb = parts > 1 ? 1u : 0u;
         B.fused_shadows = fused ? 1u : 0u;
+        B.direct_lit = direct_lit ? 1u : 0u;
         B.light_sums_f32 = ref_order ? 0u : 1u;
         B.aa_method = args->antialias_method;
         B.seed = args->seed;
@@ -1290,14 +1345,18 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             tm.end();
         }
         if (ds->has_lit) {
-            if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            if (lit_grid <= RT_LIT_OWN_OFFSET_MAX) {
-                hipLaunchKernelGGL((k_lit_scatter<true>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+            if (direct_lit) {
+                if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, Q, lit_grid);
             } else {
-                hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
-                hipLaunchKernelGGL((k_lit_scatter<false>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+                if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                if (lit_grid <= RT_LIT_OWN_OFFSET_MAX) {
+                    hipLaunchKernelGGL((k_lit_scatter<true>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+                } else {
+                    hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
+                    hipLaunchKernelGGL((k_lit_scatter<false>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+                }
+                tm.end();
             }
-            tm.end();
             // the number of lit hits is only known on the device: size the grids for the worst
             // case, surplus blocks return at once
             if (fused) {

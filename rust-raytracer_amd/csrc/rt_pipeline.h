@@ -71,10 +71,13 @@ struct RtBuffers {
     uint32_t *overflow;      // set to 1 by a traversal whose stack would have overflowed (must stay 0); never
                              // cleared by the device, so that it survives until the host looks
     uint32_t *block_counts;  // lit hits per chunk of RT_LIT_CHUNK samples (added up by the shade stage), then
-                             // their exclusive prefix sums; lies behind the counters and is cleared with them
+                             // their exclusive prefix sums (not with RtBatch::direct_lit: they stay counts); lies
+                             // behind the counters and is cleared with them
     uint32_t *counters_next; // the other of the two sets of counters and chunk counts: batches take turns with them,
                              // and a batch's first kernel zeroes the set of the batch behind it where it can
-    uint32_t *lit_list;      // samples that have a lit hit, ascending
+    uint32_t *lit_list;      // samples that have a lit hit: ascending and without gaps, counters[RT_CNT_LIT] of them;
+                             // with RtBatch::direct_lit those of chunk c in the order they were found, from
+                             // c * RT_LIT_CHUNK on, block_counts[c] of them
     uint32_t capacity;       // samples a batch can hold
     uint32_t lit_f32;        // set per frame: the lit table's vectors are stored as f32 (fast mode), see lit_store_vec
 };
@@ -104,6 +107,7 @@ struct RtBatch {
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
     uint32_t fused_shadows;  // 1: shadow rays and light sums run in one kernel that reads l_self, not the occ_* arrays
     uint32_t light_sums_f32; // 1 (fast mode): add_light<true>; 0 (reference-order mode): the reference's f64 arithmetic
+    uint32_t direct_lit;     // 1: the kernels that find lit hits list them themselves, chunk by chunk (RtBuffers::lit_list)
     int32_t aa_method;    // RT_AA_*
     uint64_t seed;        // key of the sample-offset generator
     // Order of the pixels inside a tile: in blocks of (1 << blk_w_log2) x (1 << blk_h_log2) pixels,
