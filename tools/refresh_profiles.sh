@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs HERE after tools/gpu_profile.sh has run on the GPU box for a workload: copies the small summaries of
+# gpurun_out/prof_<tag>_<workload> into profiles/<tag>_<workload>_fast.
+# Usage: tools/refresh_profiles.sh <tag> <workload> [...]
+TAG=$1; shift
+for WL in "$@"; do
+  SRC=gpurun_out/prof_${TAG}_$WL
+  DST=profiles/${TAG}_${WL}_fast
+  mkdir -p $DST
+  cp $SRC/bench.json $DST/bench.json
+  cp $SRC/summary.json $DST/pmc_summary.json
+  cp $SRC/summary.txt $DST/pmc_summary.txt
+  cp $(find $SRC/trace -name "*kernel_stats.csv" | head -n 1) $DST/kernel_stats.csv
+  cp $(find $SRC/trace_solo -name "*kernel_stats.csv" | head -n 1) $DST/kernel_stats_solo.csv
+  echo "$DST: $(ls $DST | tr '\n' ' ')"
+done
