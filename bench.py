@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 
 KERNEL_OF_CLASS = {"trace_shadow": ("k_shadow_shade_packet", "k_trace_packet<1,", "k_trace_fast<1>", "k_trace_shadow"),
-                   "trace_closest": ("k_trace_packet<0,", "k_trace_fast<0>", "k_trace_closest"),
+                   "trace_closest": ("k_camera_shade_packet", "k_bounces_fast", "k_trace_packet<0,", "k_trace_fast<0>", "k_trace_closest"),
                    "shade": ("k_shade",)}
 
 

@@ -31,6 +31,10 @@
 // kernels wait on memory most of the time, so one more resident wave is worth more than the
 // handful of values that get spilled for it -- as long as the spills stay out of the loops:
 //   packets   8 waves (64 VGPRs, no scratch since a mesh is walked with a ray variable of its own)
+//   camera rays + the stage behind them in one kernel: 7 waves (72 VGPRs, no scratch): bunny frame 0.722 / 0.706 /
+//             0.753 ms at 6 / 7 / 8 waves (at 8 the stage's f64 code spills as it does in k_shade<true>)
+//   all mirror bounces in one kernel (one ray per lane): 6 waves (80 VGPRs, 144 B of scratch); cornell_room's
+//             bounce launch 46 us at 5 waves, 49 at 6, 52 at 7 -- within noise of each other over a frame
 //   shade     behind camera rays (k_shade<true>, no loop, no queue code): 7 waves (72 VGPRs, 100 B of scratch in
 //             the box and sphere branches), bunny frame 0.192 -> 0.180 ms and cornell_room 0.512 -> 0.505 over 6
 //             waves (79 VGPRs, 12 B); at 8 waves the spills reach the triangle path and it takes twice as long;

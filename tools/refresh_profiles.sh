@@ -14,3 +14,7 @@ for WL in "$@"; do
   cp $(find $SRC/trace_solo -name "*kernel_stats.csv" | head -n 1) $DST/kernel_stats_solo.csv
   echo "$DST: $(ls $DST | tr '\n' ' ')"
 done
+# the counter figures bench.py reads (each gpu_profile.sh run merges its workload into the box's copy; the copy
+# of the run that came last holds them all)
+LAST=$(ls -t gpurun_out/prof_${TAG}_*/pmc_traffic_merged.json | head -n 1)
+cp $LAST profiles/pmc_traffic.json && echo "profiles/pmc_traffic.json <- $LAST"
