@@ -564,6 +564,12 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
             return;
         }
     }
+    // Rays that go on into bounce b + 1, added up per block and handed to the batch's counters once at the end:
+    // an add per wave and round straight to the counters is tens of thousands of atomics on a handful of
+    // addresses, which the memory side serves one after the other (8 ns each) -- as long as the kernel itself.
+    __shared__ uint32_t tally[32];
+    if (threadIdx.x < 32u) tally[threadIdx.x] = 0u;
+    __syncthreads();
     constexpr int which = 1;  // the queue of bounce 1
     const uint32_t count = Q.counters[RT_CNT_RAYS0 + 1];
     const uint32_t n_blocks = (count + RT_BLOCK - 1) / RT_BLOCK;
@@ -604,7 +610,7 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
             going = act == RT_ACT_MIRROR;
             if (going) queue_write_ray(L.Q, which, idx, tmp);
             const unsigned long long on = __ballot(going);
-            if (on != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&L.Q.counters[RT_CNT_RAYS0 + b + 1], (uint32_t)__popcll(on));
+            if (on != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&tally[b & 31], (uint32_t)__popcll(on));
             // lit hits per chunk of samples, one add per distinct chunk among the wave's lit lanes (as k_shade does)
             unsigned long long todo = __ballot(act == RT_ACT_LIT);
             const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)sample / RT_LIT_CHUNK : ~0u;
@@ -617,6 +623,99 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 31u && tally[threadIdx.x] != 0u) atomicAdd(&Q.counters[RT_CNT_RAYS0 + threadIdx.x + 1], tally[threadIdx.x]);
+}
+
+// The same with the rays of a wave walked as a packet (rt_packet.h), one wave per block: rays that leave a mirror
+// next to each other mostly stay next to each other, and a packet's walk costs a fraction of 64 separate ones.
+// Queue slots are dealt to waves in runs of 64, which is how the camera-ray kernel filled them: a run is the
+// mirror hits of one or two of its waves.  This is what the fast mode runs; RT_RENDER_NO_PACKETS keeps the
+// per-lane kernel above.  Instrumented frames, per-lane -> packets: cornell_room 0.996 -> 0.952 ms (delivered,
+// four in flight: 0.746 -> 0.702), the same room with floor and back wall mirrors 2.04 -> 1.92, every wall a
+// mirror 4.38 -> 4.33, the bunny scene with the large bunny and the ground as mirrors 4.78 -> 3.24.
+// The grid is one resident set of waves striding over the queue; with a block per packet (35 156 of them) the
+// delivered cornell_room frame takes 1.0 ms, because every block then ends with its own adds to the counters.
+#ifndef RT_BOUNCE_PACKET_WAVES
+#define RT_BOUNCE_PACKET_WAVES 7
+#endif
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_PACKET_WAVES, RT_BOUNCE_PACKET_WAVES)))
+k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
+    extern __shared__ int32_t lds[];
+    const BounceKernargsPtr args = (BounceKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    int rows;
+    {
+        const BounceKernargs &K = fresh(args);
+        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != xcd_chunk) {  // the layout assumed for the argument segment
+            *Q.overflow = 1;
+            return;
+        }
+        rows = K.S.stack_depth + 1;
+    }
+    // rays that go on into bounce b + 1, handed to the batch's counters once at the end (see k_bounces_fast):
+    // a word per bounce behind the walk's LDS
+    uint32_t *tally = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows));
+    tally[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr int which = 1;  // the queue of bounce 1
+    const uint32_t count = Q.counters[RT_CNT_RAYS0 + 1];
+    const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+    bool ok = true;
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t idx0 = blk * RT_PACKET_BLOCK + threadIdx.x;
+        bool going = idx0 < count;
+        for (int b = 1; __any(going); ++b) {
+            FastTrav st[1];
+            {
+                const BounceKernargs &K = fresh(args);
+                const uint32_t idx = opaque(idx0);
+                D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
+                float t0 = -__builtin_inff();  // a slot without a ray: an empty search interval
+                int32_t shape0 = -1, org_shape = -1, org_tri = -1;
+                if (going) {
+                    queue_read_ray(K.Q, which, idx, o, d);
+                    org_shape = K.Q.q_org_shape[which][idx];
+                    org_tri = K.Q.q_org_tri[which][idx];
+                    t0 = K.Q.q_self_t[which][idx];  // the origin primitive's own re-hit, or +inf
+                    if (t0 < __builtin_inff()) shape0 = org_shape;
+                }
+                fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
+                st[0].t = t0;
+                st[0].shape = shape0;
+                st[0].tri = -1;
+                st[0].org_shape = org_shape;
+                st[0].org_tri = org_tri;
+            }
+            ok = packet_traverse<false, 1>(S, st, closest_tmin(1), lds, rows - 1) && ok;  // (the walk's fields of S stay in registers)
+            const BounceKernargs &L = fresh(args);
+            const uint32_t idx = opaque(idx0);
+            MirrorTmp tmp;
+            int act = RT_ACT_NONE;
+            int32_t sample = 0;
+            if (going) {
+                D3 o, d;
+                sample = L.Q.q_sample[which][idx];
+                queue_read_ray(L.Q, which, idx, o, d);
+                act = shade_hit(L.S, L.Q, L.B, L.ids, b, sample, o, d, st[0].shape, st[0].tri, st[0].t, tmp);
+            }
+            going = act == RT_ACT_MIRROR;
+            if (going) queue_write_ray(L.Q, which, idx, tmp);
+            const unsigned long long on = __ballot(going);
+            if (on != 0ull && threadIdx.x == 0u) tally[b & 31] += (uint32_t)__popcll(on);
+            unsigned long long todo = __ballot(act == RT_ACT_LIT);
+            const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)sample / RT_LIT_CHUNK : ~0u;
+            while (todo != 0ull) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t of = (uint32_t)__shfl((int)chunk, leader, 64);
+                const unsigned long long same = __ballot(chunk == of);
+                wave_list_lit(L.Q, L.B.direct_lit != 0u, same, chunk == of, of, (uint32_t)sample);
+                todo &= ~same;
+            }
+        }
+    }
+    if (!ok) *fresh(args).Q.overflow = 1;
+    __syncthreads();
+    if (threadIdx.x < 31u && tally[threadIdx.x] != 0u) atomicAdd(&fresh(args).Q.counters[RT_CNT_RAYS0 + threadIdx.x + 1], tally[threadIdx.x]);
 }
 
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
@@ -1325,8 +1424,13 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             const uint32_t g = bounce == 0 ? full_grid : std::min<uint32_t>(full_grid, RT_MAX_GRID);
             if (bounce > 0 && fuse_bounce) {  // one launch follows the rays of bounce 1 through all later bounces
                 if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
-                hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);
+                if (use_packets) {  // one resident set of one-wave blocks
+                    const uint32_t gp = std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_WAVES);
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, xcd_chunk);
+                } else {
+                    const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
+                    hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);
+                }
                 tm.end();
                 break;
             }
