@@ -512,8 +512,16 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     }
     // every sample of the batch passes here exactly once: this clears the lit table where no lit hit was stored
     if (idx < count && act != RT_ACT_LIT) K.Q.l_shape[idx] = -1;
-    const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, &K.Q.counters[RT_CNT_RAYS0 + 1]);
-    if (act == RT_ACT_MIRROR) shade_commit_mirror(K.Q, 0, slot, tmp);
+    // Mirror rays go into queue 1.  With chunked_queue (the packet kernel for the bounces follows) into the stretch
+    // of the wave's chunk of samples, a counter per chunk: one counter for the whole queue is a returning atomic
+    // per wave on ONE address, served one at a time (8 ns each: 1.1 ms for a frame in which every wave sees a
+    // mirror).  Otherwise compacted behind one counter, as the separate stage does.
+    {
+        const bool chunked = K.B.chunked_queue != 0u;
+        const uint32_t chunk = idx / RT_LIT_CHUNK;
+        const uint32_t slot = wave_alloc(act == RT_ACT_MIRROR, chunked ? &K.Q.mirror_counts[chunk] : &K.Q.counters[RT_CNT_RAYS0 + 1]);
+        if (act == RT_ACT_MIRROR) shade_commit_mirror(K.Q, 0, (chunked ? chunk * RT_LIT_CHUNK : 0u) + slot, tmp);
+    }
     // Lit hits: counted per chunk of samples (the wave's 64 samples lie in one chunk) and, with direct_lit,
     // listed at once in the chunk's stretch of the lit list, at the place the count gives.
     wave_list_lit(K.Q, K.B.direct_lit != 0u, __ballot(act == RT_ACT_LIT), act == RT_ACT_LIT, idx / RT_LIT_CHUNK, idx);
@@ -640,13 +648,13 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
 #define RT_BOUNCE_PACKET_WAVES 7
 #endif
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_PACKET_WAVES, RT_BOUNCE_PACKET_WAVES)))
-k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_chunk) {
+k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples) {
     extern __shared__ int32_t lds[];
     const BounceKernargsPtr args = (BounceKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     int rows;
     {
         const BounceKernargs &K = fresh(args);
-        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != xcd_chunk) {  // the layout assumed for the argument segment
+        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != n_samples) {  // (the last argument lies where xcd_chunk does)  // the layout assumed for the argument segment
             *Q.overflow = 1;
             return;
         }
@@ -658,12 +666,18 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xc
     tally[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int which = 1;  // the queue of bounce 1
-    const uint32_t count = Q.counters[RT_CNT_RAYS0 + 1];
-    const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+    // the queue has a stretch per chunk of samples (RtBuffers::mirror_counts): the waves stride over all packets
+    // of all stretches and pass over those behind a stretch's last ray
+    constexpr uint32_t per_chunk = RT_LIT_CHUNK / RT_PACKET_BLOCK;
+    const uint32_t n_packets = (n_samples + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
     bool ok = true;
-    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const uint32_t idx0 = blk * RT_PACKET_BLOCK + threadIdx.x;
-        bool going = idx0 < count;
+    for (uint32_t blk = blockIdx.x; blk < n_packets; blk += gridDim.x) {
+        const uint32_t chunk = blk / per_chunk, first = (blk % per_chunk) * RT_PACKET_BLOCK;
+        const uint32_t queued = fresh(args).Q.mirror_counts[chunk];
+        if (first >= queued) continue;
+        const uint32_t idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
+        bool going = first + threadIdx.x < queued;
+        if (threadIdx.x == 0u) tally[0] += min(queued - first, (uint32_t)RT_PACKET_BLOCK);  // rays of bounce 1
         for (int b = 1; __any(going); ++b) {
             FastTrav st[1];
             {
@@ -701,7 +715,7 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xc
             going = act == RT_ACT_MIRROR;
             if (going) queue_write_ray(L.Q, which, idx, tmp);
             const unsigned long long on = __ballot(going);
-            if (on != 0ull && threadIdx.x == 0u) tally[b & 31] += (uint32_t)__popcll(on);
+            if (on != 0ull && threadIdx.x == 0u) tally[b & 31] += (uint32_t)__popcll(on);  // rays of bounce b + 1
             unsigned long long todo = __ballot(act == RT_ACT_LIT);
             const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)sample / RT_LIT_CHUNK : ~0u;
             while (todo != 0ull) {
@@ -715,7 +729,8 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xc
     }
     if (!ok) *fresh(args).Q.overflow = 1;
     __syncthreads();
-    if (threadIdx.x < 31u && tally[threadIdx.x] != 0u) atomicAdd(&fresh(args).Q.counters[RT_CNT_RAYS0 + threadIdx.x + 1], tally[threadIdx.x]);
+    if (threadIdx.x < 32u && tally[threadIdx.x] != 0u && RT_CNT_RAYS0 + threadIdx.x + 1 < RT_CNT_LIT)
+        atomicAdd(&fresh(args).Q.counters[RT_CNT_RAYS0 + threadIdx.x + 1], tally[threadIdx.x]);
 }
 
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
@@ -1062,7 +1077,7 @@ bool assign_buffers(RtBuffers &Q, uint32_t capacity, uint32_t n_point_lights, Ta
     get(&Q.occ_t, cap * npl);
     get(&Q.color, cap * 3);
     // the counters and, behind them, the per-chunk lit counts (one memset clears both), twice: see counters_next
-    const size_t set_words = ((size_t)RT_CNT_SIZE + cap / RT_LIT_CHUNK + 1 + 63u) & ~(size_t)63u;
+    const size_t set_words = ((size_t)RT_CNT_SIZE + 2 * (cap / RT_LIT_CHUNK + 1) + 63u) & ~(size_t)63u;
     get(&Q.counters, 2 * set_words);
     get(&Q.lit_list, cap);
     if (!ok) return false;
@@ -1367,6 +1382,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         B.compact_fb = parts > 1 ? 1u : 0u;
         B.fused_shadows = fused ? 1u : 0u;
         B.direct_lit = direct_lit ? 1u : 0u;
+        B.chunked_queue = fuse_camera && fuse_bounce ? 1u : 0u;  // k_camera_shade_packet, then k_bounces_packet
         B.light_sums_f32 = ref_order ? 0u : 1u;
         B.aa_method = args->antialias_method;
         B.seed = args->seed;
@@ -1380,7 +1396,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         // previous batch used (for the next one), so that no memset stands in front of a frame; any other batch
         // clears its own set with a memset.  (The static work array is shared by all backends of a device, so
         // nothing is known about its sets from one call to the next: always a memset.)
-        const uint32_t n_counters = (uint32_t)RT_CNT_SIZE + lit_grid;
+        const uint32_t n_counters = (uint32_t)RT_CNT_SIZE + 2u * lit_grid;  // counters, lit hits per chunk, mirror rays per chunk
         const bool clear_in_kernel = !ds->has_ggx && !ref_order && use_packets && !static_memory;
         uint32_t n_clear = 0;
         {
@@ -1401,6 +1417,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             }
             Q.counters = sets[use];
             Q.block_counts = Q.counters + RT_CNT_SIZE;
+            Q.mirror_counts = Q.block_counts + lit_grid;
             Q.counters_next = sets[use ^ 1];
         }
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
@@ -1426,7 +1443,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                 if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
                 if (use_packets) {  // one resident set of one-wave blocks
                     const uint32_t gp = std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_WAVES);
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, xcd_chunk);
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, n_samples);
                 } else {
                     const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
                     hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);

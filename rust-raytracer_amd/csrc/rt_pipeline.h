@@ -73,6 +73,8 @@ struct RtBuffers {
     uint32_t *block_counts;  // lit hits per chunk of RT_LIT_CHUNK samples (added up by the shade stage), then
                              // their exclusive prefix sums (not with RtBatch::direct_lit: they stay counts); lies
                              // behind the counters and is cleared with them
+    uint32_t *mirror_counts; // RtBatch::chunked_queue: mirror rays per chunk of RT_LIT_CHUNK samples that the camera rays left in
+                             // the chunk's stretch of queue 1 (slots from chunk * RT_LIT_CHUNK on); lies behind block_counts
     uint32_t *counters_next; // the other of the two sets of counters and chunk counts: batches take turns with them,
                              // and a batch's first kernel zeroes the set of the batch behind it where it can
     uint32_t *lit_list;      // samples that have a lit hit: ascending and without gaps, counters[RT_CNT_LIT] of them;
@@ -107,6 +109,7 @@ struct RtBatch {
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
     uint32_t fused_shadows;  // 1: shadow rays and light sums run in one kernel that reads l_self, not the occ_* arrays
     uint32_t light_sums_f32; // 1 (fast mode): add_light<true>; 0 (reference-order mode): the reference's f64 arithmetic
+    uint32_t chunked_queue;  // 1: the camera rays' mirror hits go into a stretch of queue 1 per chunk of samples (RtBuffers::mirror_counts)
     uint32_t direct_lit;     // 1: the kernels that find lit hits list them themselves, chunk by chunk (RtBuffers::lit_list)
     int32_t aa_method;    // RT_AA_*
     uint64_t seed;        // key of the sample-offset generator
