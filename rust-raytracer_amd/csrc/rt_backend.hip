@@ -644,17 +644,25 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
 // mirror 4.38 -> 4.33, the bunny scene with the large bunny and the ground as mirrors 4.78 -> 3.24.
 // The grid is one resident set of waves striding over the queue; with a block per packet (35 156 of them) the
 // delivered cornell_room frame takes 1.0 ms, because every block then ends with its own adds to the counters.
+struct BouncePacketKernargs {
+    RtSceneView S;
+    RtBuffers Q;
+    RtBatch B;
+    RtIdOut ids;
+    uint32_t n_samples;
+};
+typedef const __attribute__((address_space(4))) BouncePacketKernargs *BouncePacketKernargsPtr;
 #ifndef RT_BOUNCE_PACKET_WAVES
 #define RT_BOUNCE_PACKET_WAVES 7
 #endif
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_PACKET_WAVES, RT_BOUNCE_PACKET_WAVES)))
 k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples) {
     extern __shared__ int32_t lds[];
-    const BounceKernargsPtr args = (BounceKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const BouncePacketKernargsPtr args = (BouncePacketKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     int rows;
     {
-        const BounceKernargs &K = fresh(args);
-        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != n_samples) {  // (the last argument lies where xcd_chunk does)  // the layout assumed for the argument segment
+        const BouncePacketKernargs &K = fresh(args);
+        if (K.Q.lit_list != Q.lit_list || K.n_samples != n_samples) {  // the layout assumed for the argument segment
             *Q.overflow = 1;
             return;
         }
@@ -681,7 +689,7 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
         for (int b = 1; __any(going); ++b) {
             FastTrav st[1];
             {
-                const BounceKernargs &K = fresh(args);
+                const BouncePacketKernargs &K = fresh(args);
                 const uint32_t idx = opaque(idx0);
                 D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
                 float t0 = -__builtin_inff();  // a slot without a ray: an empty search interval
@@ -701,7 +709,7 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
                 st[0].org_tri = org_tri;
             }
             ok = packet_traverse<false, 1>(S, st, closest_tmin(1), lds, rows - 1) && ok;  // (the walk's fields of S stay in registers)
-            const BounceKernargs &L = fresh(args);
+            const BouncePacketKernargs &L = fresh(args);
             const uint32_t idx = opaque(idx0);
             MirrorTmp tmp;
             int act = RT_ACT_NONE;
