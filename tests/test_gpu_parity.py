@@ -289,7 +289,7 @@ def test_fused_and_separate_shadow_kernels_agree(rt, backend, scene_path):
     launch, RT_RENDER_UNFUSED_CAMERA a launch for the camera rays and one for their hits,
     RT_RENDER_NO_PACKETS the per-lane kernels, RT_RENDER_ROW_MAJOR_PIXELS the plain pixel order.  None of
     them may change a pixel or a count."""
-    for name in ("mixed_features", "bunny_small", "spheres_1K"):
+    for name in ("mixed_features", "bunny_small", "spheres_1K", "cornell_room"):  # (cornell_room: mirror chains to the full depth)
         scene = rt.parse_scene_file(scene_path(name), image_width=200, image_height=150, recursion_depth=6)
         dev = backend.upload(scene)
         base, ids0, st0 = dev.render(3, want_ids=True)
@@ -299,6 +299,7 @@ def test_fused_and_separate_shadow_kernels_agree(rt, backend, scene_path):
             assert np.array_equal(fb.pixels, base.pixels), (name, flags)
             assert np.array_equal(ids.shadow_shape >= 0, ids0.shadow_shape >= 0) and np.array_equal(ids.shadow_shape == -2, ids0.shadow_shape == -2)
             assert np.array_equal(ids.primary_tri, ids0.primary_tri) and st.total_rays() == st0.total_rays()
+            assert st.secondary_rays == st0.secondary_rays and st.shaded_hits == st0.shaded_hits
             for field in ("primary_shape", "final_shape", "final_tri", "bounces"):
                 assert np.array_equal(getattr(ids, field), getattr(ids0, field)), (name, flags, field)
         # frames that clear their counters in different ways, back to back on one backend and without
