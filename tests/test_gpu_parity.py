@@ -319,6 +319,31 @@ def test_fused_and_separate_shadow_kernels_agree(rt, backend, scene_path):
     b.close()
 
 
+def test_frames_of_different_sizes_share_a_backend(rt, backend, scene_path):
+    """A backend's two sets of counters are cleared for each other by whatever frame comes next: frames of
+    different sizes (different numbers of per-chunk counters), modes and kernel variants in turn, none of them
+    waiting for statistics, must each come out as when rendered alone."""
+    devs, want = [], []
+    for name, w, h in (("cornell_room", 96, 64), ("mixed_features", 320, 200), ("bunny_small", 200, 150)):  # (the second one makes the buffers grow)
+        dev = backend.upload(rt.parse_scene_file(scene_path(name), image_width=w, image_height=h, recursion_depth=6))
+        devs.append(dev)
+        want.append(dev.render(3)[0].pixels)
+    order = [(0, 0, rt.RT_MODE_FAST), (1, 0, rt.RT_MODE_FAST), (0, 0, rt.RT_MODE_FAST), (2, rt.RT_RENDER_NO_PACKETS, rt.RT_MODE_FAST),
+             (1, 0, rt.RT_MODE_FAST), (1, 0, rt.RT_MODE_FAST), (0, rt.RT_RENDER_UNFUSED_CAMERA, rt.RT_MODE_FAST), (2, 0, rt.RT_MODE_FAST),
+             (1, rt.RT_RENDER_UNFUSED_SHADOWS, rt.RT_MODE_FAST), (0, 0, rt.RT_MODE_FAST), (2, 0, rt.RT_MODE_FAST), (1, 0, rt.RT_MODE_FAST)]
+    for which, flags, mode in order:
+        fb, _, _ = devs[which].render(3, flags=flags, mode=mode, want_stats=False)
+        assert np.array_equal(fb.pixels, want[which]), (which, flags)
+    # the same with a reference-order frame (which clears its counters itself) in between; its pixels differ from
+    # the fast mode's in the last bit, so it is only there to dirty a set
+    devs[0].render(3, mode=rt.RT_MODE_REFERENCE_ORDER, want_stats=False)
+    for which in (1, 0, 2):
+        fb, _, _ = devs[which].render(3, want_stats=False)
+        assert np.array_equal(fb.pixels, want[which]), which
+    for dev in devs:
+        dev.close()
+
+
 def test_untile_of_frames_gathered_together(rt, backend, scene_path):
     """A gather that brings several frames at once leaves rank 0 with [rank][frame][block]:
     rt_untile_device_pitched restores frame f from offset f blocks with the ranks' blocks F blocks apart."""
