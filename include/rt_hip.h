@@ -170,7 +170,7 @@ typedef struct RtRenderArgs {
     /* Tuning; 0 = the library's choice everywhere.  None of them changes a pixel.
      *  batch_samples  most samples (pixels x rays per pixel) worked on at a time; a larger frame is
      *                 rendered in several batches of whole tiles (0 -> 16 Mi, about 1.9 GB of queues)
-     *  xcd_chunk      consecutive 256-sample blocks handed to one XCD (one L2) at a time
+     *  xcd_chunk      consecutive 256-sample blocks handed to one XCD (one L2) at a time (rounded down to a power of two)
      *  flags          RT_RENDER_* below */
     uint32_t batch_samples;
     uint32_t xcd_chunk;

@@ -128,12 +128,14 @@ __device__ __forceinline__ void wave_list_lit(const RtBuffers &Q, bool list, uns
 // of `chunk` consecutive logical blocks, so each L2 serves a few tiles' worth of BVH at a
 // time while the interleave keeps the XCDs evenly loaded.  Bijective on [0, n_blocks).
 // (Which physical XCD gets which residue is not defined; only the grouping matters.)
+// `chunk` is a power of two (the host sees to that): the remap is shifts and masks, where a division by a
+// number only known at run time costs some twenty instructions, four times per wave.
 __device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t b, uint32_t n_blocks, uint32_t chunk) {
-    const uint32_t span = 8u * chunk;
-    const uint32_t full = n_blocks / span * span;  // blocks covered by whole 8-chunk groups
-    if (b >= full) return b;                       // ragged tail: leave in place
-    const uint32_t group = b / span, r = b % span;
-    return group * span + (r % 8u) * chunk + r / 8u;
+    const uint32_t chunk_log2 = (uint32_t)__builtin_ctz(chunk), span_log2 = chunk_log2 + 3u;
+    const uint32_t full = (n_blocks >> span_log2) << span_log2;  // blocks covered by whole 8-chunk groups
+    if (b >= full) return b;                                     // ragged tail: leave in place
+    const uint32_t r = b & ((1u << span_log2) - 1u);
+    return (b - r) + ((r & 7u) << chunk_log2) + (r >> 3);
 }
 
 // ------------------------------------------------------------------ kernels
@@ -1442,7 +1444,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         // chunk of the XCD remap, in 256-sample blocks: 128 (a few tiles) for a whole frame, smaller
         // for a small launch so that every XCD still gets >= 32 chunks -- chunks differ in cost, and
         // with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
-        const uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, full_grid / 256u));
+        uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, full_grid / 256u));
+        while ((xcd_chunk & (xcd_chunk - 1u)) != 0u) xcd_chunk &= xcd_chunk - 1u;  // down to a power of two: the kernels shift and mask
         for (int bounce = 0; bounce <= max_bounce; ++bounce) {
             // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
             // the device, so a fixed grid strides over it (and costs little when it is empty).
