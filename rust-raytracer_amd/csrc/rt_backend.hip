@@ -100,6 +100,13 @@ __device__ __forceinline__ uint32_t wave_alloc(bool pred, uint32_t *counter) {
     return base + rank;
 }
 
+// A word that a kernel launched EARLIER left in memory, read at a wave-uniform address through the scalar cache
+// (which a kernel starts with empty): one scalar load where the compiler, which cannot know that nothing in
+// this kernel writes the word, would send the wave's vector memory unit.
+__device__ __forceinline__ uint32_t uniform_load(const uint32_t *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(reinterpret_cast<uintptr_t>(p));
+}
+
 // Lists the wave's lit hits (RtBatch::direct_lit).  `in` = the lanes whose hit is lit and lies in chunk `chunk`
 // (wave-uniform), `entry` = what such a lane lists.  Every lane of the wave must get here.  Counts the hits in
 // block_counts[chunk] in any case; with `list` the count's old value is where the wave's entries go in the
@@ -356,26 +363,32 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     bool want_ids, shadows;
     {
         const FusedKernargs &K = fresh(args);
+        // Everything the way in needs, fetched together: a third of a frame's waves find their packet of the lit
+        // list empty and leave here, and what they cost is the round trips they wait for one after the other.
+        const uint32_t *const k_lit_list = K.Q.lit_list, *const k_block_counts = K.Q.block_counts, *const k_counters = K.Q.counters;
+        const uint32_t k_chunk = K.xcd_chunk, k_direct = K.B.direct_lit;
+        const uint32_t grid = gridDim.x;
+        asm volatile("" ::"s"(k_lit_list), "s"(k_block_counts), "s"(k_counters), "s"(k_chunk), "s"(k_direct), "s"(grid));  // (all of them issued before the first wait)
         // the layout assumed above, checked against two arguments as the compiler passes them
-        if (K.Q.lit_list != Q.lit_list || K.xcd_chunk != xcd_chunk) {
+        if (k_lit_list != Q.lit_list || k_chunk != xcd_chunk) {
             *Q.overflow = 1;
             return;
         }
-        if (K.B.direct_lit) {
+        if (k_direct) {
             // The lit list has a stretch per chunk of samples, filled from its start (RtBuffers::lit_list): the grid
             // covers every stretch, and the waves behind a stretch's last entry leave.
             constexpr uint32_t per_chunk = RT_LIT_CHUNK / RT_PACKET_BLOCK;
-            const uint32_t blk = xcd_chunked_block(blockIdx.x, gridDim.x, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK);
+            const uint32_t blk = xcd_chunked_block(blockIdx.x, grid, k_chunk * RT_BLOCK / RT_PACKET_BLOCK);
             const uint32_t chunk = blk / per_chunk, first = (blk % per_chunk) * RT_PACKET_BLOCK;
-            const uint32_t listed = K.Q.block_counts[chunk];
+            const uint32_t listed = uniform_load(k_block_counts + chunk);
             if (first >= listed) return;
             count = chunk * RT_LIT_CHUNK + listed;
             idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
         } else {
-            count = K.Q.counters[RT_CNT_LIT];
+            count = uniform_load(k_counters + RT_CNT_LIT);
             const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
             if (blockIdx.x >= n_blocks) return;
-            idx0 = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+            idx0 = xcd_chunked_block(blockIdx.x, n_blocks, k_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
         }
         rows = K.S.stack_depth + 1;
         n_point_lights = K.S.n_point_lights;
@@ -683,7 +696,7 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
     bool ok = true;
     for (uint32_t blk = blockIdx.x; blk < n_packets; blk += gridDim.x) {
         const uint32_t chunk = blk / per_chunk, first = (blk % per_chunk) * RT_PACKET_BLOCK;
-        const uint32_t queued = fresh(args).Q.mirror_counts[chunk];
+        const uint32_t queued = uniform_load(fresh(args).Q.mirror_counts + chunk);
         if (first >= queued) continue;
         const uint32_t idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
         bool going = first + threadIdx.x < queued;
