@@ -319,6 +319,24 @@ def test_fused_and_separate_shadow_kernels_agree(rt, backend, scene_path):
     b.close()
 
 
+def test_tuning_arguments_change_no_pixel(rt, backend, scene_path):
+    """RtRenderArgs.xcd_chunk (any value: the library rounds it down to a power of two) and batch_samples only
+    change which wave works on what."""
+    import torch
+
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=320, image_height=200, recursion_depth=6)
+    dev = backend.upload(scene)
+    want = dev.render(3)[0].pixels
+    fb = torch.zeros(320 * 200 * 3, dtype=torch.float32, device="cuda")
+    for chunk in (1, 2, 3, 7, 8, 100, 128, 1000, 1 << 20):
+        fb.zero_()
+        dev.render_device(dev.render_args(3, xcd_chunk=chunk), fb.data_ptr())
+        backend.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(fb.cpu().numpy().reshape(200, 320, 3), want), chunk
+    dev.close()
+
+
 def test_frames_of_different_sizes_share_a_backend(rt, backend, scene_path):
     """A backend's two sets of counters are cleared for each other by whatever frame comes next: frames of
     different sizes (different numbers of per-chunk counters), modes and kernel variants in turn, none of them
