@@ -180,6 +180,16 @@ typedef struct RtRenderArgs {
      * parts rotate over the GPUs -- GPU r renders part (r + k) % N of frame k -- so that a part that costs
      * more than the others does not always fall on the same GPU. */
     uint32_t part_rotation;
+    /* render_pixel(scene, i, j, ...) -- render.rs:53-84, the reference's entry point for "these pixels"
+     * (lib.rs:21; its incremental caller renders the next n pixels with it).  A window of window_w x
+     * window_h pixels whose lower left pixel is (window_x0, window_y0) of the frame (row 0 = bottom, as in
+     * the framebuffer); window_w = 0 or window_h = 0: the whole frame.  Only the window's pixels are
+     * rendered, and every output then covers the window instead of the frame: the framebuffer holds
+     * window_w * window_h * 3 floats, pixel (i, j) of the frame at ((i - x0) + (j - y0) * window_w) * 3,
+     * and sample s of RtRayIds is ((i - x0) + (j - y0) * window_w) * n*n + p * n + q.  A pixel's value does
+     * not depend on the window it is rendered in (the stochastic sample offsets are keyed by the sample's
+     * index in the FRAME); a 1 x 1 window is render_pixel.  Whole windows only: part_count <= 1. */
+    uint32_t window_x0, window_y0, window_w, window_h;
 } RtRenderArgs;
 
 enum {
@@ -234,7 +244,7 @@ typedef struct RtStats {
 /* render(&scene, sqrt_rpp, aa, cb) -> Framebuffer  -- render.rs:7-23.
  * `fb_rgb` is caller-owned host memory, width*height*3 floats, laid out as
  * Framebuffer::pixels (framebuffer.rs:21-31): index (i + j*width)*3, row j = 0
- * is the bottom of the image.  With part_count > 1 only the owned tiles'
+ * is the bottom of the image (with RtRenderArgs.window_*: the window's pixels, see there).  With part_count > 1 only the owned tiles'
  * pixels are written.  Blocking. */
 int rt_render(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
               float *fb_rgb, const RtRayIds *ids_host, RtStats *stats_out);
@@ -263,7 +273,9 @@ int rt_backend_sync(RtBackend *backend);
  * stream, which is created non-blocking: work on it is NOT ordered with the
  * caller's null-stream work, so pass the stream that produces / consumes the
  * buffers).  Returns after enqueueing when stats_out is NULL; with stats_out it
- * waits for the stream and fills the counters and timings. */
+ * waits for the stream and fills the counters and timings.  The stream may be destroyed once the
+ * call has returned: rt_backend_sync and rt_backend_destroy wait for an event recorded behind the
+ * frame, not for the stream. */
 int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
                      float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream,
                      RtStats *stats_out);
@@ -279,7 +291,12 @@ int rt_render_device(RtBackend *backend, const RtDeviceScene *dev_scene, const R
  * (part_count <= 1); no statistics, timed_classes is ignored, progress is not called; ONE tile
  * (tile_w x tile_h x rays per pixel samples, about 240 + 12 x point lights bytes each) must fit the
  * array, else RT_ERR_INVALID.  All calls on one GPU share that GPU's array, whatever backend they go
- * through: calls that overlap on one GPU race (frames on one stream, or ordered by events, do not). */
+ * through, and the array keeps the last frame's contents (each frame clears the counters it needs).  Frames
+ * in the array therefore never overlap: the library orders them itself -- an event is recorded behind every
+ * such frame and the next one on that GPU, whatever backend and stream it comes through, begins with a
+ * wait for it on the device -- so two streams may both be used but gain nothing over one.  Two host
+ * threads inside this call for one GPU at the same time would interleave their enqueues: the second gets
+ * RT_ERR_INVALID. */
 #define RT_STATIC_SCRATCH_BYTES (64u << 20)
 int rt_render_device_static(RtBackend *backend, const RtDeviceScene *dev_scene, const RtRenderArgs *args,
                             float *fb_rgb_dev, const RtRayIds *ids_dev, void *hip_stream);

@@ -318,6 +318,34 @@ impl<'b> DeviceScene<'b> {
         Ok(stats)
     }
 
+    /// The pixels of a window of the frame (`RtRenderArgs::window_*`): `width * height` colours, row 0 at the
+    /// bottom of the window.  A pixel's value is the one it has in the whole frame.
+    pub fn render_window(&self, x0: u32, y0: u32, width: u32, height: u32, sqrt_rays_per_pixel: u16,
+                         antialias_method: AntialiasMethod, seed: u64) -> Result<Vec<[f32; 3]>, HipError> {
+        let mut args = self.args(sqrt_rays_per_pixel, antialias_method);
+        args.seed = seed; // a frame rendered piece by piece needs one seed for all its pieces
+        args.window_x0 = x0;
+        args.window_y0 = y0;
+        args.window_w = width;
+        args.window_h = height;
+        let mut pixels = vec![[0.0f32; 3]; (width as usize) * (height as usize)];
+        check(unsafe {
+            sys::rt_render(self.backend.raw, self.raw, &args, pixels.as_mut_ptr() as *mut f32, std::ptr::null(), std::ptr::null_mut())
+        })?;
+        Ok(pixels)
+    }
+
+    /// `render_pixel` (render.rs:53-84): one pixel into the caller's framebuffer -- a 1 x 1 window.
+    pub fn render_pixel(&self, fb: &mut Framebuffer, sqrt_rays_per_pixel: u16, antialias_method: AntialiasMethod, i: u32,
+                        j: u32, seed: u64, per_pixel_cb: Option<&dyn Fn()>) -> Result<(), HipError> {
+        let px = self.render_window(i, j, 1, 1, sqrt_rays_per_pixel, antialias_method, seed)?;
+        if let Some(cb) = per_pixel_cb {
+            cb();
+        }
+        fb.pixels[(i + j * fb.width) as usize] = px[0]; // Framebuffer::set_pixel, framebuffer.rs:21-31
+        Ok(())
+    }
+
     /// `render` (render.rs:7-23).  The reference allocates width x width pixels (render.rs:13); the
     /// first width x height of them are the image, and those are what the back end fills.
     pub fn render(&self, sqrt_rays_per_pixel: u16, antialias_method: AntialiasMethod, per_pixel_cb: Option<&dyn Fn()>)

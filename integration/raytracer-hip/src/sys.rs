@@ -205,6 +205,11 @@ pub struct RtRenderArgs {
     pub xcd_chunk: u32,
     pub flags: u32,
     pub part_rotation: u32,
+    /// render_pixel's counterpart (render.rs:53-84): only the pixels of this window, outputs indexed inside it.
+    pub window_x0: u32,
+    pub window_y0: u32,
+    pub window_w: u32,
+    pub window_h: u32,
 }
 
 impl RtRenderArgs {
@@ -227,6 +232,10 @@ impl RtRenderArgs {
             xcd_chunk: 0,
             flags: 0,
             part_rotation: 0,
+            window_x0: 0,
+            window_y0: 0,
+            window_w: 0,
+            window_h: 0,
         }
     }
 }

@@ -182,6 +182,10 @@ class RtRenderArgs(C.Structure):
         ("xcd_chunk", C.c_uint32),
         ("flags", C.c_uint32),
         ("part_rotation", C.c_uint32),
+        ("window_x0", C.c_uint32),
+        ("window_y0", C.c_uint32),
+        ("window_w", C.c_uint32),
+        ("window_h", C.c_uint32),
     ]
 
 
@@ -637,8 +641,10 @@ class DeviceScene:
 
     def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
                     tile=(0, 0), part=(0, 1), seed=0, part0_weight=0, batch_samples=0, xcd_chunk=0, flags=0,
-                    part_rotation=0) -> RtRenderArgs:
+                    part_rotation=0, window=None) -> RtRenderArgs:
         a = RtRenderArgs()
+        if window is not None:  # (x0, y0, w, h): only those pixels, render_pixel's counterpart (render.rs:53-84)
+            a.window_x0, a.window_y0, a.window_w, a.window_h = (int(v) for v in window)
         a.batch_samples, a.xcd_chunk, a.flags = int(batch_samples), int(xcd_chunk), int(flags)
         a.part_rotation = int(part_rotation)
         a.sqrt_rays_per_pixel = int(sqrt_rays_per_pixel)
@@ -652,21 +658,23 @@ class DeviceScene:
 
     def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
                want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None, part0_weight=0,
-               batch_samples=0, flags=0, want_stats: bool = True, out: Optional[np.ndarray] = None):
+               batch_samples=0, flags=0, want_stats: bool = True, out: Optional[np.ndarray] = None, window=None):
         """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats|None).
         `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57);
         `progress(pixels_done, pixels_total)` is called after every finished batch of tiles.
         `want_stats=False` passes no RtStats: the frame is then enqueued without an event pair around
         every kernel and waited for once.  `out`: render into this [H, W, 3] float32 array (e.g. a
-        HostBuffer's) instead of a fresh one."""
+        HostBuffer's) instead of a fresh one.  `window` = (x0, y0, w, h): render_pixel's counterpart
+        (render.rs:53-84) -- only those pixels, and the framebuffer and ids returned cover the window."""
         a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed, part0_weight,
-                             batch_samples=batch_samples, flags=flags)
+                             batch_samples=batch_samples, flags=flags, window=window)
+        out_w, out_h = (int(window[2]), int(window[3])) if window is not None and window[2] and window[3] else (self.width, self.height)
         keep = None
         if progress is not None:
             keep = PROGRESS_FN(lambda done, total, _user: progress(int(done), int(total)))
             a.progress = C.cast(keep, C.c_void_p)
-        fb = Framebuffer(self.width, self.height, out)
-        ids = RayIds(self.width * self.height * int(sqrt_rays_per_pixel) ** 2, self.n_point_lights) if want_ids else None
+        fb = Framebuffer(out_w, out_h, out)
+        ids = RayIds(out_w * out_h * int(sqrt_rays_per_pixel) ** 2, self.n_point_lights) if want_ids else None
         ids_struct = ids.as_struct() if ids is not None else None
         stats = RtStats() if want_stats else None
         _check(

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,6 +73,21 @@
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 
 namespace {
+
+// All backends of a device share that device's one static array, so the frames rendered in it must not overlap.
+// The library sees to that itself: `done` is recorded behind every such frame, and the next one -- whatever
+// backend and stream it comes through -- starts with a wait for it on the device (no host wait, no allocation).
+// `in_call` catches two host threads inside rt_render_device_static for one device at the same time, whose
+// enqueues would interleave: the second gets RT_ERR_INVALID.
+struct StaticSlot {
+    std::atomic<int> in_call{0};
+    hipEvent_t done = nullptr;  // created by the device's first rt_backend_create
+};
+#define RT_STATIC_MAX_DEVICES 64
+StaticSlot &static_slot(int device) {
+    static StaticSlot slots[RT_STATIC_MAX_DEVICES];
+    return slots[device];
+}
 
 // ------------------------------------------------------------------ device helpers
 
@@ -1159,6 +1176,20 @@ void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t par
             if (rt_tile_map_owner(map, tx, ty) == part) out.push_back((int32_t)(ty * tiles_x + tx));
 }
 
+// The pixels a render covers: RtRenderArgs' window, or the whole frame.
+struct Window {
+    uint32_t x0, y0, w, h;
+};
+int resolve_window(const RtRenderArgs *args, uint32_t W, uint32_t H, Window &win) {
+    win = Window{0, 0, W, H};
+    if (args->window_w == 0 || args->window_h == 0) return RT_OK;
+    if ((uint64_t)args->window_x0 + args->window_w > W || (uint64_t)args->window_y0 + args->window_h > H)
+        return rt::set_error(RT_ERR_INVALID, "the window sticks out of the " + std::to_string(W) + " x " + std::to_string(H) + " frame");
+    if (args->part_count > 1) return rt::set_error(RT_ERR_INVALID, "a window is rendered whole (part_count <= 1)");
+    win = Window{args->window_x0, args->window_y0, args->window_w, args->window_h};
+    return RT_OK;
+}
+
 // Shared argument check of everything that splits a frame.
 int check_partition(const RtRenderArgs *args) {
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
@@ -1272,7 +1303,10 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
     if (int bad = check_partition(args)) return bad;
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    const uint32_t W = ds->width, H = ds->height;
+    // W x H: the rendered pixels (the window, else the frame), which the tiles are laid over
+    Window win;
+    if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
+    const uint32_t W = win.w, H = win.h;
     const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
     const uint32_t spp = n * n;
     const uint64_t tile_samples = (uint64_t)tw * th * spp;
@@ -1285,7 +1319,21 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
 
     RT_HIP(hipSetDevice(be->device));
     if (!stream) stream = be->stream;
-    be->last_stream = stream;
+    struct InCall {  // rt_render_device_static: one call per device at a time (StaticSlot)
+        std::atomic<int> *flag = nullptr;
+        ~InCall() {
+            if (flag) flag->store(0);
+        }
+    } in_call;
+    if (static_memory) {
+        if (!be->scratch) return rt::set_error(RT_ERR_DEVICE, "the static work memory of this device is not available");
+        StaticSlot &slot = static_slot(be->device);
+        if (slot.in_call.exchange(1) != 0)
+            return rt::set_error(RT_ERR_INVALID, "two calls of rt_render_device_static for one GPU overlap: they share that GPU's work array");
+        in_call.flag = &slot.in_call;
+        // the frame rendered in the array before this one (any backend, any stream) ends first
+        RT_HIP(hipStreamWaitEvent(stream, slot.done, 0));
+    }
 
     // ---- tile list (cached per partition); a whole frame in static memory needs none: slot k is tile k
     if (static_memory && (parts > 1 || stats != nullptr))
@@ -1309,10 +1357,21 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     RtBuffers carved;
     if (static_memory) {
         // as many tiles as the device's static array holds; the arrays are laid out in it afresh on every call
-        if (!be->scratch) return rt::set_error(RT_ERR_DEVICE, "the static work memory of this device is not available");
+        // The largest number of tiles whose arrays fit, by bisection (the bytes grow with the tiles).  One tile's
+        // bytes are no guide to it: every array is padded to 256 bytes and the counter sets have a fixed part,
+        // some 13 KB that a batch pays once, not once per tile.
         const size_t per_tile = buffer_bytes((uint32_t)tile_samples, ds->n_point_lights);
-        uint32_t fit = (uint32_t)std::min<uint64_t>(slots_per_batch, (uint64_t)RT_STATIC_SCRATCH_BYTES / std::max<size_t>(per_tile, 1) + 1);
-        while (fit > 0 && buffer_bytes((uint32_t)(fit * tile_samples), ds->n_point_lights) > (size_t)RT_STATIC_SCRATCH_BYTES) --fit;
+        auto fits = [&](uint64_t tiles) { return buffer_bytes((uint32_t)(tiles * tile_samples), ds->n_point_lights) <= (size_t)RT_STATIC_SCRATCH_BYTES; };
+        uint32_t fit = 0;
+        if (fits(1)) {
+            uint64_t lo = 1, hi = std::min<uint64_t>(slots_per_batch, std::max<uint32_t>(n_slots, 1));  // lo fits
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi + 1) / 2;
+                if (fits(mid)) lo = mid;
+                else hi = mid - 1;
+            }
+            fit = (uint32_t)lo;
+        }
         if (fit == 0)
             return rt::set_error(RT_ERR_INVALID, "one tile of " + std::to_string(tile_samples) + " samples with " +
                                                      std::to_string(ds->n_point_lights) + " point lights needs " + std::to_string(per_tile) +
@@ -1393,6 +1452,16 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
     const bool wait_batches = stats != nullptr || serve_progress;
 
+    // Which of the backend's two counter sets is clean is noted below BEFORE the kernels that do the clearing are
+    // enqueued; any way out of this function other than the last line leaves that note untrue, so it is taken
+    // back: both sets count as dirty and the next frame clears what it uses with a memset.
+    struct DirtyGuard {
+        RtBackend *be;
+        bool armed;
+        ~DirtyGuard() {
+            if (armed) be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
+        }
+    } dirty_guard{be, !static_memory};
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
         RtBatch B{};
@@ -1400,7 +1469,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         B.slot0 = slot0;
         B.n_pixels = slots * tw * th;
         B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x;
-        B.width = W; B.height = H;
+        B.width = ds->width; B.height = ds->height;
+        B.win_x0 = win.x0; B.win_y0 = win.y0; B.win_w = win.w; B.win_h = win.h;
         B.n = n;
         B.compact_fb = parts > 1 ? 1u : 0u;
         B.fused_shadows = fused ? 1u : 0u;
@@ -1556,10 +1626,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             }
         }
     }
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) {  // a launch failed: which counters were zeroed is not known
-        be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
+    if (hipError_t e = hipGetLastError(); e != hipSuccess)  // a launch failed: which counters were zeroed is not known
         return rt::set_error(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
-    }
     if (!stats && !tm.pairs.empty()) {  // read later by rt_collect_timings
         be->deferred.insert(be->deferred.end(), tm.pairs.begin(), tm.pairs.end());
         be->deferred_stream = stream;
@@ -1592,7 +1660,16 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             }
         }
     }
-    return stats ? rt::finish_stream(be, stream) : RT_OK;
+    // A frame on a stream of the caller's: rt_backend_sync must be able to wait for it without keeping the
+    // stream's handle (the caller may destroy the stream), so an event of the backend's marks its end.
+    if (stream != be->stream) {
+        RT_HIP(hipEventRecord(be->foreign_done, stream));
+        be->foreign_pending = true;
+    }
+    if (static_memory) RT_HIP(hipEventRecord(static_slot(be->device).done, stream));  // see StaticSlot
+    rc = stats ? rt::finish_stream(be, stream) : RT_OK;
+    dirty_guard.armed = rc != RT_OK;
+    return rc;
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1615,12 +1692,22 @@ extern "C" int rt_backend_create(int device_ordinal, RtBackend **backend_out) {
     if (e == hipSuccess) e = hipHostMalloc((void **)&be->sticky_host, 64, hipHostMallocDefault);
     // the device address of this device's copy of the static work array (this device is current)
     if (e == hipSuccess) e = hipGetSymbolAddress((void **)&be->scratch, HIP_SYMBOL(scratch));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&be->foreign_done, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        if (device_ordinal < RT_STATIC_MAX_DEVICES) {
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lock(mu);
+            StaticSlot &slot = static_slot(device_ordinal);
+            if (!slot.done) e = hipEventCreateWithFlags(&slot.done, hipEventDisableTiming);
+        } else {
+            be->scratch = nullptr;  // rt_render_device_static then reports that it is not available
+        }
+    }
     if (e != hipSuccess) {
         rt_backend_destroy(be);
         return rt::set_error(RT_ERR_DEVICE, std::string("backend set-up: ") + hipGetErrorString(e));
     }
     *be->sticky_host = 0u;
-    be->last_stream = be->stream;
     *backend_out = be;
     return RT_OK;
 }
@@ -1629,7 +1716,8 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
     if (!be) return;
     (void)hipSetDevice(be->device);
     if (be->stream) (void)hipStreamSynchronize(be->stream);
-    if (be->last_stream && be->last_stream != be->stream) (void)hipStreamSynchronize(be->last_stream);
+    if (be->foreign_pending && be->foreign_done) (void)hipEventSynchronize(be->foreign_done);  // frames on the caller's streams
+    if (be->foreign_done) (void)hipEventDestroy(be->foreign_done);
     for (auto &p : be->deferred) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -1648,7 +1736,11 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
 extern "C" int rt_backend_sync(RtBackend *be) {
     if (!be) return rt::set_error(RT_ERR_INVALID, "null argument");
     RT_HIP(hipSetDevice(be->device));
-    return rt::finish_stream(be, be->last_stream ? be->last_stream : be->stream);
+    if (be->foreign_pending) {  // frames that went to a stream of the caller's: their end is marked by an event
+        RT_HIP(hipStreamWaitEvent(be->stream, be->foreign_done, 0));
+        be->foreign_pending = false;
+    }
+    return rt::finish_stream(be, be->stream);
 }
 
 extern "C" int rt_host_alloc(size_t bytes, void **ptr_out) {
@@ -1785,7 +1877,9 @@ extern "C" int rt_render_async(RtBackend *be, const RtDeviceScene *ds, const RtR
     RT_HIP(hipSetDevice(be->device));
     if (!rt::is_pinned_host(fb_rgb_pinned))
         return rt::set_error(RT_ERR_INVALID, "rt_render_async needs page-locked host memory (rt_host_alloc)");
-    const size_t fb_floats = (size_t)ds->width * ds->height * 3;
+    Window win;
+    if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
+    const size_t fb_floats = (size_t)win.w * win.h * 3;
     if (int grown = rt::ensure_device_fb(be, fb_floats)) return grown;
     if (int rc = rt::render_frame(be, ds, args, be->fb, nullptr, be->stream, nullptr, false, false)) return rc;
     RT_HIP(hipMemcpyAsync(fb_rgb_pinned, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream));
@@ -1796,7 +1890,9 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
                          const RtRayIds *ids_host, RtStats *stats_out) {
     if (!be || !ds || !args || !fb_rgb) return rt::set_error(RT_ERR_INVALID, "null argument");
     RT_HIP(hipSetDevice(be->device));
-    const size_t W = ds->width, H = ds->height;
+    Window win;
+    if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
+    const size_t W = win.w, H = win.h;  // the rendered pixels: what the outputs cover
     const size_t n = args->sqrt_rays_per_pixel;
     const size_t samples = W * H * n * n;
     const size_t fb_floats = W * H * 3;

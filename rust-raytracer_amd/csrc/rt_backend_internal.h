@@ -27,7 +27,10 @@ struct RtEventPair {
 struct RtBackend {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr;  // stream of the most recent enqueue; rt_backend_sync waits for it
+    // Recorded behind every frame that is enqueued on a stream of the caller's: rt_backend_sync and
+    // rt_backend_destroy wait for this event, never for the caller's stream, whose handle may be gone by then.
+    hipEvent_t foreign_done = nullptr;
+    bool foreign_pending = false;
     // event pairs of frames enqueued with RtRenderArgs::timed_classes, until rt_collect_timings
     std::vector<RtEventPair> deferred;
     hipStream_t deferred_stream = nullptr;

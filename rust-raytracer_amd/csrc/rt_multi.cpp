@@ -52,7 +52,8 @@ const Rccl *rccl() {
             if (api.handle) break;
         }
         if (!api.handle) {
-            api.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "unknown error");
+            const char *why = dlerror();  // once: the call hands the message over and clears it
+            api.error = std::string("librccl could not be loaded: ") + (why ? why : "unknown error");
         } else {
             bool all = true;
             auto bind = [&](auto &slot, const char *symbol) {

@@ -104,7 +104,11 @@ struct RtBatch {
     uint32_t slot0;       // first tile slot of this batch
     uint32_t n_pixels;    // local pixels (tile slots x tile_w x tile_h)
     uint32_t tile_w, tile_h, tiles_x;
-    uint32_t width, height;
+    uint32_t width, height;  // of the frame (they key the sample index of the stochastic sample offsets)
+    // The pixels that are rendered: the window (win_x0, win_y0, win_w, win_h) of the frame, which the tiles are
+    // laid over from its lower left corner; outputs (framebuffer, ids) are indexed inside the window.
+    // win_w = 0 on the way into rt_batch_finish: the whole frame.
+    uint32_t win_x0, win_y0, win_w, win_h;
     uint32_t n;           // sqrt_rays_per_pixel
     uint32_t compact_fb;  // 1: framebuffer is tile-major over the owned tiles, 0: full image layout
     uint32_t fused_shadows;  // 1: shadow rays and light sums run in one kernel that reads l_self, not the occ_* arrays
@@ -129,6 +133,11 @@ struct RtBatch {
 
 // Call once all other fields are set.
 inline void rt_batch_finish(RtBatch &B) {
+    if (B.win_w == 0 || B.win_h == 0) {
+        B.win_x0 = B.win_y0 = 0;
+        B.win_w = B.width;
+        B.win_h = B.height;
+    }
     B.div_tile_px = rt_div_make(B.tile_w * B.tile_h);
     B.div_blocks_row = rt_div_make(B.tile_w >> B.blk_w_log2);
     B.div_tiles_x = rt_div_make(B.tiles_x);
@@ -140,6 +149,8 @@ struct RtIdOut {  // RtRayIds, device pointers (any may be null)
     int32_t *primary_shape, *primary_tri, *final_shape, *final_tri, *bounces, *shadow_shape, *shadow_tri;
 };
 
+// Pixel (i, j) of the FRAME that local pixel lp of the batch is; false for the padding pixels of a tile that
+// sticks out of the rendered window.
 RT_HD bool batch_pixel(const RtBatch &B, uint32_t lp, uint32_t &i, uint32_t &j) {
     const uint32_t in_batch = rt_div(lp, B.div_tile_px), r = lp - in_batch * B.div_tile_px.d;
     const uint32_t tile = B.tile_list ? (uint32_t)B.tile_list[B.slot0 + in_batch] : B.slot0 + in_batch;
@@ -149,17 +160,23 @@ RT_HD bool batch_pixel(const RtBatch &B, uint32_t lp, uint32_t &i, uint32_t &j) 
     const uint32_t x = (blk_x << B.blk_w_log2) + (in_blk & ((1u << B.blk_w_log2) - 1u));
     const uint32_t y = (blk_y << B.blk_h_log2) + (in_blk >> B.blk_w_log2);
     const uint32_t tile_y = rt_div(tile, B.div_tiles_x), tile_x = tile - tile_y * B.div_tiles_x.d;
-    i = tile_x * B.tile_w + x;
-    j = tile_y * B.tile_h + y;
-    return i < B.width && j < B.height;
+    const uint32_t wi = tile_x * B.tile_w + x, wj = tile_y * B.tile_h + y;  // inside the window
+    i = B.win_x0 + wi;
+    j = B.win_y0 + wj;
+    return wi < B.win_w && wj < B.win_h;
 }
 
-// Global sample index of RtRayIds for a local sample.
+// Index of frame pixel (i, j) in the outputs, which cover the rendered window.
+RT_HD size_t output_pixel(const RtBatch &B, uint32_t i, uint32_t j) {
+    return (size_t)(i - B.win_x0) + (size_t)(j - B.win_y0) * B.win_w;
+}
+
+// Sample index of RtRayIds (inside the rendered window) for a local sample.
 RT_HD size_t global_sample(const RtBatch &B, uint32_t ls) {
     const uint32_t lp = rt_div(ls, B.div_spp);
     uint32_t i, j;
     batch_pixel(B, lp, i, j);
-    return ((size_t)i + (size_t)j * B.width) * B.div_spp.d + (ls - lp * B.div_spp.d);
+    return output_pixel(B, i, j) * B.div_spp.d + (ls - lp * B.div_spp.d);
 }
 
 RT_HD int32_t tri_file_index(const RtSceneView &S, int32_t gtri) {
@@ -576,9 +593,9 @@ RT_HD bool resolve_address(const RtBatch &B, uint32_t lp, float *fb, float *&px)
     if (!batch_pixel(B, lp, i, j)) return false;
     if (B.compact_fb) {
         const uint32_t tp = B.tile_w * B.tile_h;  // tiles are stored row-major whatever the order they were worked in
-        px = fb + ((size_t)(B.slot0 + rt_div(lp, B.div_tile_px)) * tp + (size_t)(j % B.tile_h) * B.tile_w + i % B.tile_w) * 3;
+        px = fb + ((size_t)(B.slot0 + rt_div(lp, B.div_tile_px)) * tp + (size_t)((j - B.win_y0) % B.tile_h) * B.tile_w + (i - B.win_x0) % B.tile_w) * 3;
     } else {
-        px = fb + ((size_t)i + (size_t)j * B.width) * 3;
+        px = fb + output_pixel(B, i, j) * 3;
     }
     return true;
 }

@@ -152,6 +152,25 @@ def test_missing_library_is_an_error_not_a_fallback(tmp_path):
     assert "ERR -4" in out
 
 
+def test_rccl_that_cannot_be_loaded_is_an_error_not_a_crash():
+    """librccl is mapped on demand (rt_multi.cpp); when that fails, rt_comm_id reports RT_ERR_DEVICE with
+    the loader's message, on the first call and on every later one.  The load is made to fail by capping
+    the process's address space just above what it already uses: the library is hundreds of megabytes."""
+    code = ("import ctypes as C, importlib, resource\n"
+            "rt = importlib.import_module('rust-raytracer_amd')\n"
+            "L = rt.lib()\n"
+            "vm = int([l for l in open('/proc/self/status') if l.startswith('VmSize')][0].split()[1]) * 1024\n"
+            "resource.setrlimit(resource.RLIMIT_AS, (vm + (32 << 20), vm + (32 << 20)))\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "for _ in range(2):\n"
+            "    print('RC', L.rt_comm_id(buf), L.rt_last_error().decode())\n")
+    out = subprocess.check_output(["python3", "-c", code], cwd=ROOT).decode().splitlines()
+    lines = [l for l in out if l.startswith("RC ")]
+    assert len(lines) == 2, out
+    for l in lines:
+        assert l.startswith("RC -4 librccl could not be loaded: ") and len(l) > len("RC -4 librccl could not be loaded: "), l
+
+
 def test_product_does_not_reach_into_the_oracle(rt):
     """The shipped library and package must not link, import or name the test oracle."""
     deps = subprocess.check_output(["ldd", rt.LIB_PATH]).decode()

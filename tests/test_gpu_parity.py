@@ -496,6 +496,66 @@ def test_headline_workload_matches_oracle_at_full_size(rt, backend, scene_path):
     dev.close()
 
 
+def test_window_render_equals_the_same_pixels_of_the_whole_frame(rt, backend, scene_path):
+    """RtRenderArgs.window_* -- the counterpart of render_pixel (render.rs:53-84): the pixels of a window are
+    the whole frame's pixels bit for bit, ids included, for every sample-offset method, in both modes, for
+    windows that do and do not line up with the tiles, down to one pixel; through rt_render, rt_render_device
+    and rt_render_async.  The window is also compared with the oracle's render of that window."""
+    import torch
+
+    W, H, n = 200, 150, 3
+    spp = n * n
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=4)
+    dev = backend.upload(scene)
+    npl = dev.n_point_lights
+    windows = [(0, 0, W, H), (64, 32, 32, 32), (37, 11, 101, 77), (199, 149, 1, 1), (0, 140, 200, 10), (123, 45, 1, 1)]
+    seed = 0xFEEDBEEF
+    for aa in (0, 1, 2):
+        for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+            whole, wids, wstats = dev.render(n, antialias_method=aa, mode=mode, want_ids=True, seed=seed)
+            for win in windows:
+                x0, y0, ww, wh = win
+                fb, ids, stats = dev.render(n, antialias_method=aa, mode=mode, want_ids=True, seed=seed, window=win)
+                assert fb.pixels.shape == (wh, ww, 3)
+                assert np.array_equal(fb.pixels, whole.pixels[y0:y0 + wh, x0:x0 + ww]), (aa, mode, win)
+                assert stats.primary_rays == ww * wh * spp
+                for f in rt.ID_FIELDS:
+                    per = npl if f.startswith("shadow") else 1
+                    full = getattr(wids, f).reshape(H, W, spp * per)[y0:y0 + wh, x0:x0 + ww].reshape(-1)
+                    got = getattr(ids, f).reshape(-1)
+                    if f.startswith("shadow") and mode == rt.RT_MODE_FAST:  # the first blocker met: hidden or not
+                        full, got = np.minimum(full, 0), np.minimum(got, 0)
+                    assert np.array_equal(got, full), (aa, mode, win, f)
+    # against the oracle's window (which is indexed the same way)
+    win = (37, 11, 101, 77)
+    ref_fb, ref_ids, counters = oracle_lib.render(scene, n, want_ids=True, aa=1, seed=seed, window=win)
+    fb, ids, stats = dev.render(n, antialias_method=1, mode=rt.RT_MODE_REFERENCE_ORDER, want_ids=True, seed=seed, window=win)
+    parity.assert_parity(fb.pixels, ids, ref_fb, ref_ids, label="window vs oracle window")
+    assert [stats.primary_rays, stats.secondary_rays, stats.shadow_rays] == counters["rays"]
+    # the device entry point and the enqueue-only one
+    whole, _, _ = dev.render(n, seed=seed)
+    x0, y0, ww, wh = win
+    a = dev.render_args(n, seed=seed, window=win)
+    out = torch.zeros(ww * wh * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    dev.render_device(a, out.data_ptr())
+    backend.sync()
+    assert np.array_equal(out.cpu().numpy().reshape(wh, ww, 3), whole.pixels[y0:y0 + wh, x0:x0 + ww])
+    host = rt.HostBuffer((wh, ww, 3))
+    dev.render_async(a, host)
+    backend.sync()
+    assert np.array_equal(host.array, whole.pixels[y0:y0 + wh, x0:x0 + ww])
+    host.close()
+    # what a window may not be
+    for bad in ((150, 0, 51, 10), (0, 149, 10, 2), (2 ** 32 - 1, 0, 2, 1)):
+        with pytest.raises(rt.RtError) as e:
+            dev.render(n, window=bad)
+        assert e.value.code == rt.RT_ERR_INVALID
+    with pytest.raises(rt.RtError):
+        dev.render(n, window=(0, 0, 64, 64), part=(0, 2))
+    dev.close()
+
+
 def test_4k_rpp64_config_whole_and_in_eight_parts(rt, backend, scene_path):
     """bunny 3840x2160, 64 rays per pixel, depth 6 (530.8 M camera rays, 32 batches of 16 Mi samples):
     the frame rendered whole equals the frame rendered as 8 interleaved parts and un-tiled, bit for
@@ -554,6 +614,10 @@ def test_4k_rpp64_config_whole_and_in_eight_parts(rt, backend, scene_path):
                 assert same_sh[cast].mean() >= parity.ID_MATCH_MIN, (mode, w, same_sh[cast].mean())
             m = parity.image_metrics(image[y0:y0 + wh, x0:x0 + ww], ref_fb)
             assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, (mode, w, m)
+            # the same window rendered directly (RtRenderArgs.window_*): the frame's pixels, bit for bit
+            direct, direct_ids, _ = dev.render(n, mode=mode, want_ids=True, tile=(tile, tile), window=w)
+            assert np.array_equal(direct.pixels, image[y0:y0 + wh, x0:x0 + ww]), (mode, w)
+            assert np.array_equal(direct_ids.primary_shape, got_shape) and np.array_equal(direct_ids.primary_tri, got_tri)
     assert parity.image_metrics(whole_pixels[0][0], whole_pixels[1][0])["lsb1_fraction"] >= parity.LSB_MATCH_MIN
     del prim_shape, prim_tri, sh_shape, sh_tri
 

@@ -73,3 +73,37 @@ def test_static_memory_render_equals_the_allocating_one(rt, backend, scene_path)
     ok, _, _ = dev.render(2)  # the backend is still usable
     assert ok.pixels.any()
     dev.close()
+
+
+def test_static_memory_frames_on_two_streams_do_not_overlap(rt, backend, scene_path):
+    """All backends of a GPU share its one static array.  Frames enqueued back to back through two backends on
+    two streams, with no ordering of the caller's between them, must still come out right: the library makes
+    each frame wait (on the device) for the frame that used the array before it.  Small tiles, so that the
+    frames run in many batches each and would trample each other's queues if they overlapped."""
+    import torch
+
+    scenes = [rt.parse_scene_file(scene_path("cornell_room"), image_width=480, image_height=360, recursion_depth=6),
+              rt.parse_scene_file(scene_path("bunny_small"), image_width=400, image_height=300, recursion_depth=6)]
+    other = rt.Backend(0)
+    bes = [backend, other]
+    devs = [bes[k].upload(scenes[k]) for k in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    args = [devs[k].render_args(3, tile=(16, 16), batch_samples=16 * 16 * 9 * 40) for k in range(2)]
+    want = [torch.zeros(devs[k].width * devs[k].height * 3, dtype=torch.float32, device="cuda") for k in range(2)]
+    got = [[torch.full_like(want[k], -1.0) for _ in range(3)] for k in range(2)]
+    torch.cuda.synchronize()
+    for k in range(2):
+        devs[k].render_device(args[k], want[k].data_ptr())
+        bes[k].sync()
+    for r in range(3):
+        for k in range(2):  # alternating backends and streams, nothing waited for in between
+            devs[k].render_device_static(args[k], got[k][r].data_ptr(), stream=streams[k].cuda_stream)
+    for k in range(2):
+        bes[k].sync()
+    torch.cuda.synchronize()
+    for k in range(2):
+        for r in range(3):
+            assert torch.equal(got[k][r], want[k]), (k, r)
+    for d in devs:
+        d.close()
+    other.close()
