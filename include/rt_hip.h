@@ -190,6 +190,18 @@ typedef struct RtRenderArgs {
      * not depend on the window it is rendered in (the stochastic sample offsets are keyed by the sample's
      * index in the FRAME); a 1 x 1 window is render_pixel.  Whole windows only: part_count <= 1. */
     uint32_t window_x0, window_y0, window_w, window_h;
+    /* Several parts of the frame in ONE set of launches (part_count > 1; 0 or 1: the one part part_index).
+     * The call renders the parts part_index, part_index + 1, ... (mod part_count), part_span of them; part
+     * (part_index + j) % part_count leaves its compact block of tiles (as it would alone) at
+     * part_span_pitch_floats * j floats into the framebuffer (0: tiles_owned_max * tile_w * tile_h * 3, the blocks
+     * end to end as a gather buffer holds them; else a whole number of tiles, at least that).  The tiles of all
+     * these parts are worked on together in image order.  For a GPU whose share of a frame is so small that the
+     * fixed cost of a frame's launches -- a kernel lasts as long as its slowest wave -- rivals the share itself:
+     * what it owes a group of frames it can then render in fewer, larger launches.  No counterpart in the
+     * reference.  rt_render scatters the pixels of all these parts; not for rt_render_async / _static. */
+    uint32_t part_span;
+    uint32_t _reserved0;
+    uint64_t part_span_pitch_floats;
 } RtRenderArgs;
 
 enum {

@@ -210,6 +210,10 @@ pub struct RtRenderArgs {
     pub window_y0: u32,
     pub window_w: u32,
     pub window_h: u32,
+    /// Several parts of the frame in one set of launches (multi-GPU streams of frames).
+    pub part_span: u32,
+    pub _reserved0: u32,
+    pub part_span_pitch_floats: u64,
 }
 
 impl RtRenderArgs {
@@ -236,6 +240,9 @@ impl RtRenderArgs {
             window_y0: 0,
             window_w: 0,
             window_h: 0,
+            part_span: 0,
+            _reserved0: 0,
+            part_span_pitch_floats: 0,
         }
     }
 }

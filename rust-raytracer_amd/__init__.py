@@ -186,6 +186,9 @@ class RtRenderArgs(C.Structure):
         ("window_y0", C.c_uint32),
         ("window_w", C.c_uint32),
         ("window_h", C.c_uint32),
+        ("part_span", C.c_uint32),
+        ("_reserved0", C.c_uint32),
+        ("part_span_pitch_floats", C.c_uint64),
     ]
 
 
@@ -641,8 +644,9 @@ class DeviceScene:
 
     def render_args(self, sqrt_rays_per_pixel, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
                     tile=(0, 0), part=(0, 1), seed=0, part0_weight=0, batch_samples=0, xcd_chunk=0, flags=0,
-                    part_rotation=0, window=None) -> RtRenderArgs:
+                    part_rotation=0, window=None, part_span=0, part_span_pitch_floats=0) -> RtRenderArgs:
         a = RtRenderArgs()
+        a.part_span, a.part_span_pitch_floats = int(part_span), int(part_span_pitch_floats)
         if window is not None:  # (x0, y0, w, h): only those pixels, render_pixel's counterpart (render.rs:53-84)
             a.window_x0, a.window_y0, a.window_w, a.window_h = (int(v) for v in window)
         a.batch_samples, a.xcd_chunk, a.flags = int(batch_samples), int(xcd_chunk), int(flags)
@@ -658,7 +662,8 @@ class DeviceScene:
 
     def render(self, sqrt_rays_per_pixel: int, antialias_method=AntialiasMethod.Normal, mode=RT_MODE_FAST,
                want_ids: bool = False, tile=(0, 0), part=(0, 1), seed=0, progress=None, part0_weight=0,
-               batch_samples=0, flags=0, want_stats: bool = True, out: Optional[np.ndarray] = None, window=None):
+               batch_samples=0, flags=0, want_stats: bool = True, out: Optional[np.ndarray] = None, window=None,
+               part_span=0):
         """render(&scene, sqrt_rpp, aa, cb) -- render.rs:7-23.  Returns (Framebuffer, RayIds|None, RtStats|None).
         `seed` keys the sample offsets of the Jittered / Random methods (antialias.rs:45-57);
         `progress(pixels_done, pixels_total)` is called after every finished batch of tiles.
@@ -667,7 +672,7 @@ class DeviceScene:
         HostBuffer's) instead of a fresh one.  `window` = (x0, y0, w, h): render_pixel's counterpart
         (render.rs:53-84) -- only those pixels, and the framebuffer and ids returned cover the window."""
         a = self.render_args(sqrt_rays_per_pixel, antialias_method, mode, tile, part, seed, part0_weight,
-                             batch_samples=batch_samples, flags=flags, window=window)
+                             batch_samples=batch_samples, flags=flags, window=window, part_span=part_span)
         out_w, out_h = (int(window[2]), int(window[3])) if window is not None and window[2] and window[3] else (self.width, self.height)
         keep = None
         if progress is not None:

@@ -162,6 +162,25 @@ __device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t b, uint32_t n_blo
     return (b - r) + ((r & 7u) << chunk_log2) + (r >> 3);
 }
 
+// Development builds only (-DRT_WAVE_TIMELINE, tools/wave_timeline.py): every wave of the two packet kernels that
+// finds work notes when it started and ended (the 100 MHz constant clock) in a log the tool hands over, entry =
+// packet index (+ the camera kernel's grid for the shadow kernel): the shape of a kernel's tail, wave by wave.
+#ifdef RT_WAVE_TIMELINE
+__device__ unsigned long long *g_wave_log;
+__device__ __forceinline__ void wave_log(uint32_t entry, unsigned long long t0) {
+    const unsigned long long t1 = wall_clock64();
+    if (g_wave_log != nullptr && threadIdx.x == 0u) {
+        g_wave_log[2 * (size_t)entry] = t0;
+        g_wave_log[2 * (size_t)entry + 1] = t1;
+    }
+}
+#define RT_WAVE_T0() const unsigned long long wave_t0 = wall_clock64()
+#define RT_WAVE_LOG(entry) wave_log((entry), wave_t0)
+#else
+#define RT_WAVE_T0() ((void)0)
+#define RT_WAVE_LOG(entry) ((void)0)
+#endif
+
 // ------------------------------------------------------------------ kernels
 
 // idx = local sample at bounce 0 (count = samples of the batch, passed by the host),
@@ -412,6 +431,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         want_ids = K.ids.shadow_shape != nullptr || K.ids.shadow_tri != nullptr;
         shadows = !K.S.disable_shadows;
     }
+    RT_WAVE_T0();
     uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows)) + threadIdx.x;  // behind the walk's LDS
     *hidden_slot = 0u;
     bool ok = true;
@@ -463,6 +483,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         const uint32_t sample = K.Q.lit_list[idx];
         accumulate_masked<true>(K.S, K.Q, sample, RT_STREAM_LD(K.Q.l_shape[sample]), *hidden_slot);  // fast mode only
     }
+    RT_WAVE_LOG(gridDim.x + blockIdx.x);
 }
 
 // Camera rays AND the stage behind them in one kernel (fast mode): the wave walks the tree with its 64 camera
@@ -503,6 +524,7 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     // The sample's point on the image plane waits in LDS behind the walk's rows, a column of four words per
     // lane: the ray is needed again for the hit point, and the plane point is the expensive part of it
     // (index arithmetic and four f64 divisions) while the walk has no register to spare for it.
+    RT_WAVE_T0();
     int32_t *plane = lds + rt_packet_lds_dwords(rows) + threadIdx.x;
     FastTrav st[1];
     bool live;
@@ -557,6 +579,7 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     // Lit hits: counted per chunk of samples (the wave's 64 samples lie in one chunk) and, with direct_lit,
     // listed at once in the chunk's stretch of the lit list, at the place the count gives.
     wave_list_lit(K.Q, K.B.direct_lit != 0u, __ballot(act == RT_ACT_LIT), act == RT_ACT_LIT, idx / RT_LIT_CHUNK, idx);
+    RT_WAVE_LOG(blockIdx.x);
 }
 
 // ALL mirror bounces in one kernel (fast mode): a lane takes a ray from the first bounce's queue, follows it
@@ -927,16 +950,21 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 // consecutive in memory, as consecutive floats (RT_RESOLVE_ROUND samples per pixel at a time), puts them
 // into a table in LDS whose row length is odd (no bank conflicts), and each lane then adds up its own
 // row in the same order as before: same sums, bit for bit.
+// One-wave blocks: with frames in flight this kernel runs beside the packet kernels of other frames, whose
+// one-wave blocks take every wave slot the moment it frees; a 256-thread block needs a free slot on all four
+// SIMDs of one compute unit at the same moment and waited for it (a 1/8 frame's resolve, 5 us alone, took 170 us
+// with eight frames in flight, and its stream's next frame waited with it).
 #define RT_RESOLVE_ROUND 9
 #define RT_RESOLVE_ROW (3 * RT_RESOLVE_ROUND)  // odd
-__global__ void __launch_bounds__(RT_BLOCK) k_resolve(RtBuffers Q, RtBatch B, float *fb) {
-    __shared__ float stage[RT_BLOCK / 64][64 * RT_RESOLVE_ROW];
+#define RT_RESOLVE_BLOCK 64
+__global__ void __launch_bounds__(RT_RESOLVE_BLOCK) k_resolve(RtBuffers Q, RtBatch B, float *fb) {
+    __shared__ float stage[RT_RESOLVE_BLOCK / 64][64 * RT_RESOLVE_ROW];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float *st = stage[wave];
     const uint32_t spp = B.n * B.n;
     const uint32_t n_groups = (B.n_pixels + 63u) / 64u;
     const float div = (float)(uint16_t)(B.n * B.n);
-    for (uint32_t g0 = blockIdx.x * (RT_BLOCK / 64); g0 < n_groups; g0 += gridDim.x * (RT_BLOCK / 64)) {  // the same trips for the whole block
+    for (uint32_t g0 = blockIdx.x * (RT_RESOLVE_BLOCK / 64); g0 < n_groups; g0 += gridDim.x * (RT_RESOLVE_BLOCK / 64)) {  // the same trips for the whole block
         const uint32_t group = g0 + wave;
         const uint32_t lp = group * 64u + lane;
         const bool mine = group < n_groups && lp < B.n_pixels;
@@ -1176,6 +1204,15 @@ void owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t part, uint32_t par
             if (rt_tile_map_owner(map, tx, ty) == part) out.push_back((int32_t)(ty * tiles_x + tx));
 }
 
+// Tiles per part of the split (rt_tile_map).
+std::vector<uint32_t> part_tile_counts(uint32_t tiles_x, uint32_t tiles_y, uint32_t parts, uint32_t part0_weight) {
+    std::vector<uint32_t> per_part(std::max<uint32_t>(parts, 1), 0);
+    const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, part0_weight);
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_map_owner(map, tx, ty)]++;
+    return per_part;
+}
+
 // The pixels a render covers: RtRenderArgs' window, or the whole frame.
 struct Window {
     uint32_t x0, y0, w, h;
@@ -1338,15 +1375,49 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // ---- tile list (cached per partition); a whole frame in static memory needs none: slot k is tile k
     if (static_memory && (parts > 1 || stats != nullptr))
         return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames (part_count <= 1) and no statistics");
-    const uint32_t key[6] = {W, H, tw, th, args->part_index, parts | (args->part0_weight << 24)};
+    // Several parts in one set of launches (RtRenderArgs::part_span): the tiles of all of them, in image order, each
+    // with the place it goes to -- part (part_index + j) % parts writes its compact block j * pitch tiles into the
+    // framebuffer.  One part: slot k of the list goes to place k.
+    const uint32_t span = parts > 1 ? std::max<uint32_t>(args->part_span, 1) : 1;
+    if (span > parts) return rt::set_error(RT_ERR_INVALID, "part_span exceeds part_count");
+    if (span > 1 && static_memory) return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames");
+    uint32_t pitch_tiles = 0;
+    if (span > 1) {
+        const std::vector<uint32_t> counts = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight);
+        const uint32_t most = *std::max_element(counts.begin(), counts.end());
+        const uint64_t tile_floats = (uint64_t)tw * th * 3;
+        if (args->part_span_pitch_floats % tile_floats != 0)
+            return rt::set_error(RT_ERR_INVALID, "part_span_pitch_floats must be a whole number of tiles");
+        pitch_tiles = args->part_span_pitch_floats ? (uint32_t)(args->part_span_pitch_floats / tile_floats) : most;
+        if (pitch_tiles < most) return rt::set_error(RT_ERR_INVALID, "part_span_pitch_floats smaller than a part's block of tiles");
+    }
+    const uint32_t key[8] = {W, H, tw, th, args->part_index, parts | (args->part0_weight << 24), span, pitch_tiles};
     if (!static_memory && (std::memcmp(key, be->tile_key, sizeof(key)) != 0 || !be->tile_list)) {
-        owned_tiles(tiles_x, tiles_y, args->part_index, parts, args->part0_weight, be->tile_list_host);
+        std::vector<int32_t> &tiles = be->tile_list_host, &places = be->tile_place_host;
+        places.clear();
+        if (span <= 1) {
+            owned_tiles(tiles_x, tiles_y, args->part_index, parts, args->part0_weight, tiles);
+        } else {
+            std::vector<std::pair<int32_t, int32_t>> all;  // (tile, place)
+            std::vector<int32_t> one;
+            for (uint32_t j = 0; j < span; ++j) {
+                owned_tiles(tiles_x, tiles_y, (args->part_index + j) % parts, parts, args->part0_weight, one);
+                for (size_t k = 0; k < one.size(); ++k) all.emplace_back(one[k], (int32_t)(j * pitch_tiles + k));
+            }
+            std::sort(all.begin(), all.end());  // image order: neighbouring tiles are worked on together
+            tiles.clear();
+            for (const auto &e : all) {
+                tiles.push_back(e.first);
+                places.push_back(e.second);
+            }
+        }
         if (be->tile_list) (void)hipFree(be->tile_list);
         be->tile_list = nullptr;
-        RT_HIP(hipMalloc((void **)&be->tile_list, std::max<size_t>(be->tile_list_host.size(), 1) * sizeof(int32_t)));
-        if (!be->tile_list_host.empty())
-            RT_HIP(hipMemcpy(be->tile_list, be->tile_list_host.data(), be->tile_list_host.size() * sizeof(int32_t),
-                             hipMemcpyHostToDevice));
+        // the tiles, and behind them their places if they have any
+        const size_t count = tiles.size();
+        RT_HIP(hipMalloc((void **)&be->tile_list, std::max<size_t>(2 * count, 1) * sizeof(int32_t)));
+        if (count) RT_HIP(hipMemcpy(be->tile_list, tiles.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!places.empty()) RT_HIP(hipMemcpy(be->tile_list + count, places.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
         std::memcpy(be->tile_key, key, sizeof(key));
     }
     const uint32_t n_slots = static_memory ? tiles_x * tiles_y : (uint32_t)be->tile_list_host.size();
@@ -1466,6 +1537,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
         RtBatch B{};
         B.tile_list = static_memory ? nullptr : be->tile_list;
+        B.tile_place = !static_memory && !be->tile_place_host.empty() ? be->tile_list + be->tile_list_host.size() : nullptr;
         B.slot0 = slot0;
         B.n_pixels = slots * tw * th;
         B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x;
@@ -1601,7 +1673,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         }
         }
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-        hipLaunchKernelGGL(k_resolve, dim3(grid_for(B.n_pixels)), dim3(RT_BLOCK), 0, stream, Q, B, fb_dev);
+        hipLaunchKernelGGL(k_resolve, dim3((uint32_t)std::min<uint64_t>(((uint64_t)B.n_pixels + 63u) / 64u, 4u * RT_MAX_GRID)), dim3(RT_RESOLVE_BLOCK), 0,
+                           stream, Q, B, fb_dev);
         tm.end();
 
         if (wait_batches) {
@@ -1675,6 +1748,14 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
 // ------------------------------------------------------------------ C ABI
 
 extern "C" const char *rt_last_error(void) { return rt::last_error_slot().c_str(); }
+
+#ifdef RT_WAVE_TIMELINE
+// development builds only: where the packet kernels log their waves' start and end times (nullptr: nowhere)
+extern "C" int rt_debug_wave_log(void *log_dev) {
+    RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log), &log_dev, sizeof(log_dev)));
+    return RT_OK;
+}
+#endif
 
 extern "C" int rt_backend_create(int device_ordinal, RtBackend **backend_out) {
     if (!backend_out) return rt::set_error(RT_ERR_INVALID, "null argument");
@@ -1900,7 +1981,13 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
     const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
     const uint32_t tiles_x = ((uint32_t)W + tw - 1) / tw, tiles_y = ((uint32_t)H + th - 1) / th;
     // a partitioned render lands tile-major (edge tiles padded), so size for whole tiles
-    const size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
+    size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
+    if (parts > 1 && args->part_span > 1) {  // the span's blocks, a pitch apart
+        const std::vector<uint32_t> counts = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight <= 8 ? args->part0_weight : 0);
+        const size_t pitch = args->part_span_pitch_floats ? (size_t)args->part_span_pitch_floats
+                                                          : (size_t)*std::max_element(counts.begin(), counts.end()) * tw * th * 3;
+        dev_floats = std::max(dev_floats, pitch * args->part_span);
+    }
     if (int grown = rt::ensure_device_fb(be, dev_floats)) return grown;
 
     // device mirrors of the requested id arrays
@@ -1948,7 +2035,10 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
         return rt::set_error(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     };
     // what to bring over: the frame, or the owned tiles of a part (tile-major, scattered below)
-    const size_t copy_floats = parts > 1 ? be->tile_list_host.size() * tw * th * 3 : fb_floats;
+    // (with part_span the parts' blocks lie a pitch apart: up to the last place that holds a tile)
+    size_t places = be->tile_list_host.size();
+    for (int32_t at : be->tile_place_host) places = std::max(places, (size_t)at + 1);
+    const size_t copy_floats = parts > 1 ? places * tw * th * 3 : fb_floats;
     const bool direct = parts <= 1 && rt::is_pinned_host(fb_rgb);  // the device can write the caller's memory itself
     float *landing = fb_rgb;
     if (!direct) {
@@ -1976,8 +2066,9 @@ extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderA
             const uint32_t tile = (uint32_t)be->tile_list_host[s];
             const uint32_t x0 = (tile % tiles_x) * tw, y0 = (tile / tiles_x) * th;
             const uint32_t w_in = std::min<uint32_t>(tw, (uint32_t)W - x0), h_in = std::min<uint32_t>(th, (uint32_t)H - y0);
+            const size_t at = be->tile_place_host.empty() ? s : (size_t)be->tile_place_host[s];
             for (uint32_t y = 0; y < h_in; ++y)
-                std::memcpy(fb_rgb + ((size_t)x0 + (size_t)(y0 + y) * W) * 3, landing + (s * tw * th + (size_t)y * tw) * 3,
+                std::memcpy(fb_rgb + ((size_t)x0 + (size_t)(y0 + y) * W) * 3, landing + (at * tw * th + (size_t)y * tw) * 3,
                             (size_t)w_in * 3 * sizeof(float));
         }
     } else if (!direct) {
@@ -1994,10 +2085,7 @@ extern "C" int rt_partition_info(uint32_t width, uint32_t height, const RtRender
     const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
     if (int bad = check_partition(args)) return bad;
     const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
-    std::vector<uint32_t> per_part(parts, 0);
-    const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, args->part0_weight);
-    for (uint32_t ty = 0; ty < tiles_y; ++ty)
-        for (uint32_t tx = 0; tx < tiles_x; ++tx) per_part[rt_tile_map_owner(map, tx, ty)]++;
+    const std::vector<uint32_t> per_part = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight);
     if (tiles_total) *tiles_total = tiles_x * tiles_y;
     if (tiles_owned) *tiles_owned = per_part[args->part_index];
     if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());

@@ -50,7 +50,8 @@ struct RtBackend {
     // tile list of the last partition
     int32_t *tile_list = nullptr;
     std::vector<int32_t> tile_list_host;
-    uint32_t tile_key[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<int32_t> tile_place_host;  // with RtRenderArgs::part_span > 1: where in the framebuffer each listed tile goes
+    uint32_t tile_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // tile -> position lookup of rt_untile_device
     uint32_t *tile_where = nullptr;
     uint32_t untile_key[5] = {0, 0, 0, 0, 0};

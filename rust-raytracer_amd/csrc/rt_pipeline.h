@@ -101,6 +101,7 @@ enum {
 // slot0 + lp / (tile_w*tile_h); tile_list maps a slot to the row-major tile index.
 struct RtBatch {
     const int32_t *tile_list;  // null: every tile is owned, slot k is tile k
+    const int32_t *tile_place; // compact framebuffer only: the tile of slot k is stored at place tile_place[k] (null: at place k)
     uint32_t slot0;       // first tile slot of this batch
     uint32_t n_pixels;    // local pixels (tile slots x tile_w x tile_h)
     uint32_t tile_w, tile_h, tiles_x;
@@ -593,7 +594,8 @@ RT_HD bool resolve_address(const RtBatch &B, uint32_t lp, float *fb, float *&px)
     if (!batch_pixel(B, lp, i, j)) return false;
     if (B.compact_fb) {
         const uint32_t tp = B.tile_w * B.tile_h;  // tiles are stored row-major whatever the order they were worked in
-        px = fb + ((size_t)(B.slot0 + rt_div(lp, B.div_tile_px)) * tp + (size_t)((j - B.win_y0) % B.tile_h) * B.tile_w + (i - B.win_x0) % B.tile_w) * 3;
+        const uint32_t slot = B.slot0 + rt_div(lp, B.div_tile_px);
+        px = fb + ((size_t)(B.tile_place ? (uint32_t)B.tile_place[slot] : slot) * tp + (size_t)((j - B.win_y0) % B.tile_h) * B.tile_w + (i - B.win_x0) % B.tile_w) * 3;
     } else {
         px = fb + output_pixel(B, i, j) * 3;
     }

@@ -185,6 +185,54 @@ def test_partitioned_render_and_untile_are_bit_exact(rt, backend, scene_path, pa
     dev.close()
 
 
+@pytest.mark.parametrize("parts,first,span,weight", [(8, 2, 2, 0), (8, 7, 3, 0), (4, 1, 4, 0), (8, 6, 2, 5), (3, 2, 2, 0)])
+def test_several_parts_in_one_set_of_launches(rt, backend, scene_path, parts, first, span, weight):
+    """RtRenderArgs.part_span: the parts first, first + 1, ... (mod parts) rendered by ONE call leave, block by
+    block, exactly what each of them leaves when rendered alone -- at the default pitch (blocks end to end, as in
+    a gather buffer) and at a larger one -- with the same rays in total; through rt_render the call fills the
+    pixels of all these parts."""
+    import torch
+
+    W, H, tile, n = 250, 170, 16, 2
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=6)
+    dev = backend.upload(scene)
+    a = dev.render_args(n, tile=(tile, tile), part=(0, parts), part0_weight=weight)
+    total, owned, stride = dev.partition_info(a)
+    part_floats = stride * tile * tile * 3
+    alone = torch.full((span * part_floats,), -1.0, dtype=torch.float32, device="cuda")  # (padding pixels of edge tiles stay unwritten)
+    torch.cuda.synchronize()
+    rays = 0
+    for j in range(span):
+        a = dev.render_args(n, tile=(tile, tile), part=((first + j) % parts, parts), part0_weight=weight)
+        rays += dev.render_device(a, alone.data_ptr() + j * part_floats * 4, want_stats=True).total_rays()
+    for pitch_tiles in (0, stride + 3):
+        pitch = (pitch_tiles or stride) * tile * tile * 3
+        together = torch.full((span * pitch,), -1.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        a = dev.render_args(n, tile=(tile, tile), part=(first, parts), part0_weight=weight, part_span=span,
+                            part_span_pitch_floats=pitch_tiles * tile * tile * 3)
+        st = dev.render_device(a, together.data_ptr(), want_stats=True)
+        assert st.total_rays() == rays
+        for j in range(span):
+            aj = dev.render_args(n, tile=(tile, tile), part=((first + j) % parts, parts), part0_weight=weight)
+            used = dev.partition_info(aj)[1] * tile * tile * 3
+            assert torch.equal(together[j * pitch: j * pitch + used], alone[j * part_floats: j * part_floats + used]), (pitch_tiles, j)
+            assert bool((together[j * pitch + used: (j + 1) * pitch] == -1.0).all())  # nothing written beyond a part's tiles
+    # the host entry point: the pixels of all the span's parts, and only those
+    merged = np.zeros((H, W, 3), np.float32)
+    for j in range(span):
+        fbp, _, _ = dev.render(n, tile=(tile, tile), part=((first + j) % parts, parts), part0_weight=weight)
+        merged += fbp.pixels
+    both, _, st = dev.render(n, tile=(tile, tile), part=(first, parts), part0_weight=weight, part_span=span)
+    assert np.array_equal(both.pixels, merged) and st.total_rays() == rays
+    # refused: a span longer than the split, a pitch that is no whole number of tiles or too small
+    for kw in ({"part_span": parts + 1}, {"part_span": 2, "part_span_pitch_floats": 100}, {"part_span": 2, "part_span_pitch_floats": tile * tile * 3}):
+        with pytest.raises(rt.RtError) as e:
+            dev.render_device(dev.render_args(n, tile=(tile, tile), part=(0, parts), **kw), alone.data_ptr())
+        assert e.value.code == rt.RT_ERR_INVALID
+    dev.close()
+
+
 @pytest.mark.parametrize("n,weight", [(2, 0), (5, 6)])
 def test_render_multi_in_one_process(rt, scene_path, n, weight):
     """rt_multi_create / rt_render_multi: n backends (here on one device), one host thread each, the tiles

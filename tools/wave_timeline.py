@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""When the waves of the two packet kernels of a frame start and end (a development build of the library,
+-DRT_WAVE_TIMELINE, logs them): how long the waves run, and how many are resident over the kernel's time.
+
+    make -C rust-raytracer_amd/csrc timeline        (here; the .so travels to the GPU box)
+    python3 tools/wave_timeline.py [workload] [parts] [part]
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["RT_HIP_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "librt_hip_timeline.so")
+
+
+def describe(name, t0, t1, slots):
+    import numpy as np
+
+    live = t1 > 0
+    t0, t1 = t0[live].astype(np.int64), t1[live].astype(np.int64)
+    if t0.size == 0:
+        print(name, "no waves")
+        return
+    base = t0.min()
+    t0, t1 = (t0 - base) * 10, (t1 - base) * 10  # ns
+    dur = t1 - t0
+    end = t1.max()
+    q = np.percentile(dur, [50, 90, 99, 99.9, 100]) / 1e3
+    print(f"{name}: {t0.size} waves with work, kernel span {end / 1e3:.1f} us; wave duration us: median {q[0]:.1f} p90 {q[1]:.1f} "
+          f"p99 {q[2]:.1f} p99.9 {q[3]:.1f} max {q[4]:.1f}; sum {dur.sum() / 1e3:.0f} us = {dur.sum() / end / slots:.3f} of {slots} slots")
+    # resident waves over time, in 20 steps
+    steps = 20
+    edges = np.linspace(0, end, steps + 1)
+    occ = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        overlap = np.clip(np.minimum(t1, b) - np.maximum(t0, a), 0, None).sum() / (b - a)
+        occ.append(overlap)
+    print("   resident waves per twentieth of the span:", " ".join(f"{o:.0f}" for o in occ))
+    # when the last wave STARTS, and what runs after that
+    print(f"   last start at {t0.max() / 1e3:.1f} us; waves still running 10/20/40 us before the end: "
+          f"{(t1 > end - 10000).sum()} {(t1 > end - 20000).sum()} {(t1 > end - 40000).sum()}")
+
+
+def main():
+    import numpy as np
+    import torch
+
+    workload = sys.argv[1] if len(sys.argv) > 1 else "bunny"
+    parts = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    part = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    bench = importlib.import_module("bench")
+    rt = importlib.import_module("rust-raytracer_amd")
+    importlib.import_module("scenes.gen_scenes").ensure_models()
+    scene_name, W, H, n, depth, tile, _ = bench.WORKLOADS[workload]
+    scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
+                                recursion_depth=depth)
+    be = rt.Backend(0)
+    dev = be.upload(scene)
+    a = dev.render_args(n, tile=(tile, tile), part=(part, parts))
+    _, owned, stride = dev.partition_info(a)
+    packets = -(-owned * tile * tile * n * n // 64)
+    log = torch.zeros(4 * packets + 64, dtype=torch.int64, device="cuda")
+    fb = torch.zeros(W * H * 3 + tile * tile * 3 * 700, dtype=torch.float32, device="cuda")
+    L = rt.lib()
+    L.rt_debug_wave_log.argtypes = [C.c_void_p]
+    for _ in range(5):
+        dev.render_device(a, fb.data_ptr())
+        be.sync()
+    log.zero_()
+    torch.cuda.synchronize()
+    assert L.rt_debug_wave_log(C.c_void_p(log.data_ptr())) == 0
+    dev.render_device(a, fb.data_ptr())
+    be.sync()
+    torch.cuda.synchronize()
+    assert L.rt_debug_wave_log(None) == 0
+    v = log.cpu().numpy()
+    cam = v[:2 * packets].reshape(-1, 2)
+    sh = v[2 * packets:4 * packets].reshape(-1, 2)
+    print(f"{workload}, part {part} of {parts}: {packets} packets")
+    describe("camera rays + shade", cam[:, 0], cam[:, 1], 1024 * 7)
+    describe("shadow rays + light sums", sh[:, 0], sh[:, 1], 1024 * 8)
+    both0 = np.concatenate([cam[:, 0], sh[:, 0]])
+    both1 = np.concatenate([cam[:, 1], sh[:, 1]])
+    describe("both kernels", both0, both1, 1024 * 8)
+    dev.close()
+    be.close()
+
+
+if __name__ == "__main__":
+    main()
