@@ -380,6 +380,9 @@ int rt_render_multi(RtMulti *multi, const RtRenderArgs *args, float *fb_rgb, RtS
 #define RT_COMM_ID_BYTES 128
 typedef struct RtComm RtComm;
 int rt_comm_id(uint8_t id_out[RT_COMM_ID_BYTES]);
+/* The version code of the RCCL library the communicators run on (ncclGetVersion: major * 10000 + minor * 100 +
+ * patch), which loads it if no communicator has yet.  For a benchmark's record; no counterpart in the reference. */
+int rt_comm_rccl_version(int *version_out);
 int rt_comm_create(RtBackend *backend, const uint8_t id[RT_COMM_ID_BYTES], uint32_t rank, uint32_t world,
                    RtComm **comm_out);
 void rt_comm_destroy(RtComm *comm);

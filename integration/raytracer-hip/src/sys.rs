@@ -318,6 +318,7 @@ extern "C" {
     pub fn rt_multi_destroy(multi: *mut RtMulti);
     pub fn rt_render_multi(multi: *mut RtMulti, args: *const RtRenderArgs, fb_rgb: *mut f32, stats_out: *mut RtStats) -> c_int;
     pub fn rt_comm_id(id_out: *mut u8) -> c_int;
+    pub fn rt_comm_rccl_version(version_out: *mut c_int) -> c_int;
     pub fn rt_comm_create(backend: *mut RtBackend, id: *const u8, rank: u32, world: u32, comm_out: *mut *mut RtComm) -> c_int;
     pub fn rt_comm_destroy(comm: *mut RtComm);
     pub fn rt_comm_gather(comm: *mut RtComm, part_dev: *const f32, floats: usize, gathered_dev: *mut f32, root: u32,

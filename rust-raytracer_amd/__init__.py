@@ -289,6 +289,7 @@ def lib() -> C.CDLL:
     L.rt_multi_destroy.restype = None
     L.rt_render_multi.argtypes = [vp, C.POINTER(RtRenderArgs), vp, C.POINTER(RtStats)]
     L.rt_comm_id.argtypes = [vp]
+    L.rt_comm_rccl_version.argtypes = [C.POINTER(C.c_int)]
     L.rt_comm_create.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rt_comm_destroy.argtypes = [vp]
     L.rt_comm_destroy.restype = None
@@ -372,6 +373,15 @@ class Multi:
 
 class Comm:
     """rt_comm_*: this process's end of the RCCL communicator of a one-process-per-GPU launch."""
+
+    @staticmethod
+    def rccl_version() -> int:
+        """rt_comm_rccl_version: ncclGetVersion of the RCCL the library's communicators use."""
+        lib()
+        _share_rccl_with_torch()
+        v = C.c_int()
+        _check(lib().rt_comm_rccl_version(C.byref(v)))
+        return int(v.value)
 
     @staticmethod
     def make_id() -> bytes:

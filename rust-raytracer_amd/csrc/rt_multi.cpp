@@ -35,6 +35,7 @@ struct Rccl {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     std::string error;
 };
 
@@ -72,6 +73,7 @@ const Rccl *rccl() {
             bind(api.Send, "ncclSend");
             bind(api.Recv, "ncclRecv");
             bind(api.GetErrorString, "ncclGetErrorString");
+            bind(api.GetVersion, "ncclGetVersion");
             if (!all) api.handle = nullptr;
         }
     }
@@ -100,6 +102,15 @@ struct RtComm {
     ncclComm_t comm = nullptr;
     uint32_t rank = 0, world = 1;
 };
+
+extern "C" int rt_comm_rccl_version(int *version_out) {
+    if (!version_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+    *version_out = 0;
+    const Rccl *api = rccl();
+    if (!api) return RT_ERR_DEVICE;
+    RT_NCCL(api, api->GetVersion(version_out));
+    return RT_OK;
+}
 
 extern "C" int rt_comm_id(uint8_t id_out[RT_COMM_ID_BYTES]) {
     if (!id_out) return rt::set_error(RT_ERR_INVALID, "null argument");
