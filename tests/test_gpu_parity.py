@@ -876,6 +876,10 @@ def test_bench_multi_gpu_path_with_one_rank(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 1e9
     assert "rt_comm_gather" in line["config"]["gather"]
+    # what a first run on several GPUs is read by: which exchange ran, on which RCCL, and what each phase cost a rank
+    assert line["exchange"] == "library" and isinstance(line["rccl_version"], int) and line["rccl_version"] > 20000
+    for key in ("render_ms", "exchange_ms", "untile_copy_ms"):
+        assert line["per_rank_ms"][key]["max"] >= line["per_rank_ms"][key]["min"] > 0.0, (key, line["per_rank_ms"])
     # the harness's fallback for a node on which the library's communicator does not come up: the same sends
     # and receives through torch.distributed, flagged in the line
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "2",
@@ -883,7 +887,7 @@ def test_bench_multi_gpu_path_with_one_rank(tmp_path):
                          capture_output=True, text=True, timeout=170)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["config"]["gather"].startswith("FALLBACK") and line["value"] > 1e9
+    assert line["config"]["gather"].startswith("FALLBACK") and line["value"] > 1e9 and line["exchange"] == "torch-fallback"
 
 
 def test_bench_launches_its_own_ranks_and_rotates_the_root(tmp_path):
@@ -907,6 +911,7 @@ def test_bench_launches_its_own_ranks_and_rotates_the_root(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 3 and line["config"]["rccl_ranks"] == 3 and line["steps"] == 20
     assert line["config"]["parts"].startswith("fixed")  # three ranks do not divide four frames in flight
+    assert line["exchange"] == "gloo" and line["per_rank_ms"]["render_ms"]["min"] > 0.0
     assert "bit-identical" in line["config"]["frame_check"] and "each of the 3 ranks" in line["config"]["frame_check"]
     # two ranks: the number of ranks divides the frames in flight, so the parts also rotate over the ranks
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",

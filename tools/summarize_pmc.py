@@ -110,6 +110,11 @@ def main():
                                "valu_wave_insts": cc.get("SQ_INSTS_VALU"),
                                "scalar_insts": (cc.get("SQ_INSTS_SALU", 0.0) + cc.get("SQ_INSTS_SMEM", 0.0) + cc.get("SQ_INSTS_BRANCH", 0.0)) or None,
                                "waves": cc.get("SQ_WAVES"),
+                               # busy and wait counters as collected (bench.py's roofline_issue / roofline_l2 are computed from these)
+                               "valu_active_quad_cycles": cc.get("SQ_ACTIVE_INST_VALU"), "salu_cycles": cc.get("SQ_INST_CYCLES_SALU"),
+                               "smem_cycles": cc.get("SQ_INST_CYCLES_SMEM"), "branch_insts": cc.get("SQ_INSTS_BRANCH"),
+                               "wait_any": cc.get("SQ_WAIT_ANY"), "wave_cycles": cc.get("SQ_WAVE_CYCLES"), "tcc_req": cc.get("TCC_REQ_sum"),
+                               "scalar_cache_hit_rate": (cc["SQC_DCACHE_HITS"] / cc["SQC_DCACHE_REQ"]) if cc.get("SQC_DCACHE_REQ") else None,
                                "frame_hbm_bytes": frame_bytes, "launches_per_frame": launches_per_frame,
                                "durations_from": trace_dir,
                                "bytes": dd["hbm_read_bytes"] + dd["hbm_write_bytes"], "avg_us": timed[dom]["avg_us"],
