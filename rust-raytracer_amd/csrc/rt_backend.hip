@@ -395,6 +395,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     extern __shared__ int32_t lds[];
     const FusedKernargsPtr args = (FusedKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t count, idx0;
+    uint32_t sample0 = 0u;  // the lane's entry of the lit list
     int rows, n_point_lights;
     bool want_ids, shadows;
     {
@@ -416,15 +417,20 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
             constexpr uint32_t per_chunk = RT_LIT_CHUNK / RT_PACKET_BLOCK;
             const uint32_t blk = xcd_chunked_block(blockIdx.x, grid, k_chunk * RT_BLOCK / RT_PACKET_BLOCK);
             const uint32_t chunk = blk / per_chunk, first = (blk % per_chunk) * RT_PACKET_BLOCK;
+            idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
+            // The lane's list entry is asked for BEFORE the chunk's count is known (the slot exists whether or not it
+            // has been filled): the two round trips then pass side by side, and a wave that has work -- two in three --
+            // starts its record fetches one round trip earlier.
+            sample0 = k_lit_list[idx0];
             const uint32_t listed = uniform_load(k_block_counts + chunk);
             if (first >= listed) return;
             count = chunk * RT_LIT_CHUNK + listed;
-            idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
         } else {
             count = uniform_load(k_counters + RT_CNT_LIT);
             const uint32_t n_blocks = (count + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;  // blocks that have work; the rest leave
             if (blockIdx.x >= n_blocks) return;
             idx0 = xcd_chunked_block(blockIdx.x, n_blocks, k_chunk * RT_BLOCK / RT_PACKET_BLOCK) * RT_PACKET_BLOCK + threadIdx.x;
+            if (idx0 < count) sample0 = k_lit_list[idx0];
         }
         rows = K.S.stack_depth + 1;
         n_point_lights = K.S.n_point_lights;
@@ -434,28 +440,45 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     RT_WAVE_T0();
     uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows)) + threadIdx.x;  // behind the walk's LDS
     *hidden_slot = 0u;
+    // What every light's shadow ray needs of the lane's lit hit -- the point, the primitive it lies on, the lights that
+    // primitive hides by itself -- is fetched from the lit table ONCE and waits in LDS, three pairs per lane behind the
+    // word above: fetched again per light it was a chain of two memory round trips (list entry, then the record: 2-3 us)
+    // at the head of every walk, and 28 bytes per sample and light more from HBM (the work buffers bypass the L2).
+    rt_f2 *rec = reinterpret_cast<rt_f2 *>(lds + rt_packet_lds_dwords(rows) + RT_PACKET_BLOCK) + threadIdx.x;  // [3][64] pairs
+    const bool live = idx0 < count;
+    if (shadows) {
+        const FusedKernargs &K = fresh(args);
+        float px = 0.0f, py = 0.0f, pz = 0.0f;
+        int32_t org_shape = -1, org_tri = -1;
+        uint32_t self_mask = ~0u;  // a slot without a hit traces nothing
+        if (live) {
+            const uint32_t sample = sample0;
+            org_shape = RT_STREAM_LD(K.Q.l_shape[sample]);
+            org_tri = RT_STREAM_LD(K.Q.l_tri[sample]);
+            self_mask = RT_STREAM_LD(K.Q.l_self[sample]);
+            px = RT_STREAM_LD(reinterpret_cast<const float *>(K.Q.l_p[0])[sample]);  // stored as f32: the fused kernel is fast mode's
+            py = RT_STREAM_LD(reinterpret_cast<const float *>(K.Q.l_p[1])[sample]);
+            pz = RT_STREAM_LD(reinterpret_cast<const float *>(K.Q.l_p[2])[sample]);
+        }
+        rec[0 * RT_PACKET_BLOCK] = rt_pair(px, py);
+        rec[1 * RT_PACKET_BLOCK] = rt_pair(pz, rt_as_float((int32_t)self_mask));
+        rec[2 * RT_PACKET_BLOCK] = rt_pair(rt_as_float(org_shape), rt_as_float(org_tri));
+    }
     bool ok = true;
     if (shadows) {
         for (int ls = 0; ls < n_point_lights; ++ls) {
-            const uint32_t idx = opaque(idx0);
-            const bool live = idx < count;
             FastTrav st[1];
             bool self = false;
             {
                 const FusedKernargs &K = fresh(args);
                 D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
-                int32_t org_shape = -1, org_tri = -1;
-                bool trace = false;
-                if (live) {
-                    const uint32_t sample = K.Q.lit_list[idx];
-                    org_shape = RT_STREAM_LD(K.Q.l_shape[sample]);
-                    org_tri = RT_STREAM_LD(K.Q.l_tri[sample]);
-                    self = ((RT_STREAM_LD(K.Q.l_self[sample]) >> ls) & 1u) != 0u;
-                    trace = !self;
-                    if (trace) {
-                        o = lit_load_vec(K.Q.l_p, sample, true);  // the fused kernel is fast mode's
-                        d = d3(K.S.lights[K.S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
-                    }
+                const rt_f2 r0 = rec[0 * RT_PACKET_BLOCK], r1 = rec[1 * RT_PACKET_BLOCK], r2 = rec[2 * RT_PACKET_BLOCK];
+                const int32_t org_shape = rt_as_int(r2.x), org_tri = rt_as_int(r2.y);
+                self = (((uint32_t)rt_as_int(r1.y) >> ls) & 1u) != 0u;
+                const bool trace = !self;
+                if (trace) {
+                    o = D3{(double)r0.x, (double)r0.y, (double)r1.x};
+                    d = d3(K.S.lights[K.S.point_lights[ls]].position) - o;  // Ray::atob, ray.rs:15-20
                 }
                 fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
                 st[0].t = trace ? 1.0f : -__builtin_inff();  // Hit::to_light's bound, or an empty search interval
@@ -465,7 +488,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
                 st[0].org_tri = org_tri;
             }
             ok = packet_traverse<true, 1>(S, st, (float)RT_VERY_SMALL_NUMBER, lds, rows - 1) && ok;  // (the walk's fields of S stay in registers)
-            if (st[0].shape >= 0 || self) *hidden_slot |= 1u << ls;
+            if (live && (st[0].shape >= 0 || self)) *hidden_slot |= 1u << ls;
             if (want_ids && live) {
                 const FusedKernargs &K = fresh(args);
                 const uint32_t sample = K.Q.lit_list[opaque(idx0)];
@@ -481,7 +504,17 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     const uint32_t idx = opaque(idx0);
     if (idx < count) {
         const uint32_t sample = K.Q.lit_list[idx];
-        accumulate_masked<true>(K.S, K.Q, sample, RT_STREAM_LD(K.Q.l_shape[sample]), *hidden_slot);  // fast mode only
+        D3 p;
+        int32_t shape;
+        if (shadows) {  // point and primitive wait in LDS
+            const rt_f2 r0 = rec[0 * RT_PACKET_BLOCK], r1 = rec[1 * RT_PACKET_BLOCK], r2 = rec[2 * RT_PACKET_BLOCK];
+            p = D3{(double)r0.x, (double)r0.y, (double)r1.x};
+            shape = rt_as_int(r2.x);
+        } else {
+            p = lit_load_vec(K.Q.l_p, sample, true);
+            shape = RT_STREAM_LD(K.Q.l_shape[sample]);
+        }
+        accumulate_masked<true>(K.S, K.Q, sample, shape, p, *hidden_slot);  // fast mode only
     }
     RT_WAVE_LOG(gridDim.x + blockIdx.x);
 }
@@ -1517,7 +1550,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
     constexpr int packet_rays = 1;
     // stack rows, the world-space rays of a wave inside an instance, and (fused kernel) a word per lane
-    const size_t packet_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 64u) * sizeof(int32_t);  // + the fused kernel's word per lane
+    const size_t packet_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 7u * 64u) * sizeof(int32_t);  // + the fused kernel's seven words per lane
     const size_t camera_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 4u * 64u) * sizeof(int32_t);  // + the plane point
     // a wait per batch: to read the counters for the statistics, or to serve the progress callback
     const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;

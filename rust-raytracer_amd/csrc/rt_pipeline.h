@@ -180,6 +180,15 @@ RT_HD size_t global_sample(const RtBatch &B, uint32_t ls) {
     return output_pixel(B, i, j) * B.div_spp.d + (ls - lp * B.div_spp.d);
 }
 
+// Index of a local sample in the whole FRAME, (i + j * width) * n*n + p * n + q: what keys the counter-based random
+// numbers, so that a pixel does not depend on the window or part it is rendered in.
+RT_HD uint64_t frame_sample(const RtBatch &B, uint32_t ls) {
+    const uint32_t lp = rt_div(ls, B.div_spp);
+    uint32_t i, j;
+    batch_pixel(B, lp, i, j);
+    return ((uint64_t)i + (uint64_t)j * B.width) * B.div_spp.d + (ls - lp * B.div_spp.d);
+}
+
 RT_HD int32_t tri_file_index(const RtSceneView &S, int32_t gtri) {
     return gtri < 0 ? -1 : reinterpret_cast<const RtTri *>(S.tris)[gtri].orig;
 }
@@ -529,9 +538,9 @@ RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint
 // sample had a lit hit (callers normally only pass such samples).
 // The same sum for a lit sample whose shadow rays were traced by the caller: bit k of `blocked` = point
 // light k (in scene order among the point lights) is hidden.
+// `p`: the hit point as the lit table holds it (the caller has it at hand).
 template <bool F32>
-RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, uint32_t blocked) {
-    const D3 p = lit_load_vec(Q.l_p, sample, F32);
+RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, const D3 &p, uint32_t blocked) {
     const RtShader &sh = S.shaders[S.shapes[shape].shader];
     const D3 n = lit_load_vec(Q.l_n, sample, F32);
     const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, F32) : D3{0.0, 0.0, -1.0};

@@ -235,7 +235,7 @@ RT_HD void tree_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B,
     const size_t gs = global_sample(B, ls);
     int32_t ps, pt;
     bool ok = true;
-    const ColorF c = tree_sample<Stack, FAST>(S, stk, o, d, (uint64_t)gs, B.seed, ps, pt, counts, ok);
+    const ColorF c = tree_sample<Stack, FAST>(S, stk, o, d, frame_sample(B, ls), B.seed, ps, pt, counts, ok);
     if (!ok) *Q.overflow = 1;
     write_color(Q, (int32_t)ls, c.r, c.g, c.b);
     // of the per-sample ids only the camera ray's hit is defined for a tree

@@ -751,6 +751,9 @@ def test_ggx_ray_trees_match_oracle(rt, backend, mode):
         part, _, _ = dev.render(2, mode=mode, seed=2024, tile=(16, 16), part=(p, 3))
         whole += part.pixels
     assert np.array_equal(whole, fb.pixels)
+    # nor on the window it is rendered in: the random numbers of a ray tree are keyed by the sample's index in the frame
+    win, _, _ = dev.render(2, mode=mode, seed=2024, window=(37, 20, 50, 41))
+    assert np.array_equal(win.pixels, fb.pixels[20:61, 37:87])
     dev.close()
 
 
