@@ -119,23 +119,40 @@ struct TreeFrame {  // a GGX hit waiting for its reflected rays (ggx_mirror.rs:6
     int32_t shape, tri, depth;
 };
 
-// render.rs:64-74 for one sample: the colour render_pixel adds to the pixel's sum.
-// `sample_index` = frame-wide sample index (the generator's counter), `draws` = pairs drawn so far.
-template <class Stack, bool FAST>
-RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t sample_index, uint64_t seed,
-                         int32_t &primary_shape, int32_t &primary_tri, TreeCounts &counts, bool &ok) {
+// render.rs:64-74 for one sample, as a walk that can be taken one ray at a time: begin() takes the camera ray, every
+// step() traces ONE ray of the sample's tree (and the shadow rays of the hit it finds, if that hit is lit) and returns
+// true once the colour that render_pixel adds to the pixel's sum is known.  The order of the rays, of the random draws
+// and of every sum is the order of the reference's recursion, whoever calls step() and however other samples' steps
+// are interleaved with it; `draws` counts the pairs drawn so far, `sample_index` is the frame-wide sample index (the
+// generator's counter).
+struct TreeWalk {
     TreeFrame frames[RT_TREE_MAX_DEPTH];
-    int top = -1;
-    uint32_t draws = 0;
-    int32_t depth = 0, org_shape = -1, org_tri = -1;
-    float tmin = 1.0f, self_t = __builtin_inff();
-    const ColorF background = {S.background[0], S.background[1], S.background[2]};
-    primary_shape = primary_tri = -1;
-    ColorF ret = background;
-    for (;;) {
+    D3 o, d;
+    uint64_t sample_index;
+    int32_t top, depth, org_shape, org_tri;
+    uint32_t draws;
+    float tmin, self_t;
+    int32_t primary_shape, primary_tri;
+
+    RT_HD void begin(const D3 &origin, const D3 &direction, uint64_t sample) {
+        o = origin;
+        d = direction;
+        sample_index = sample;
+        top = -1;
+        draws = 0;
+        depth = 0;
+        org_shape = org_tri = -1;
+        tmin = 1.0f;
+        self_t = __builtin_inff();
+        primary_shape = primary_tri = -1;
+    }
+
+    template <class Stack, bool FAST>
+    RT_HD bool step(const RtSceneView &S, Stack &stk, uint64_t seed, TreeCounts &counts, bool &ok, ColorF &out) {
+        const ColorF background = {S.background[0], S.background[1], S.background[2]};
+        ColorF ret = background;
         // ---- trace the current ray and shade its hit: ends in a colour (ret) or in another ray
-        bool have_ret = true;  // false: a perfect mirror replaced the current ray by its reflection
-        bool deliver = true;   // false: a GGX hit was pushed and `ret` holds nothing
+        bool deliver = true;  // false: a GGX hit was pushed and `ret` holds nothing
         float tf;
         int32_t shape, gtri;
         ok = tree_trace<Stack, FAST>(S, stk, o, d, tmin, __builtin_inff(), false, self_t, org_shape, org_tri, tf, shape, gtri) && ok;
@@ -159,20 +176,9 @@ RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t 
                 if (depth >= S.recursion_depth) {  // perfect_mirror.rs:10-12, ggx_mirror.rs:56-58
                     ret = background;
                 } else if (sh.type == RT_SHADER_PERFECT_MIRROR) {  // a tail call: its colour is the child's
-                    const D3 out = mirror_direction(d, n);
+                    const D3 out_dir = mirror_direction(d, n);      // the mirror ray (perfect_mirror.rs:18-27)
                     o = p;
-                    d = out;
-                    have_ret = false;
-                } else {
-                    top += 1;
-                    TreeFrame &f = frames[top];
-                    f.p = p; f.n = n; f.incoming = normalize(d);
-                    f.acc = ColorF{0.0f, 0.0f, 0.0f};
-                    f.k = 0; f.samples = sh.samples; f.alpha = sh.roughness;
-                    f.shape = shape; f.tri = gtri; f.depth = depth;
-                    deliver = false;  // nothing to hand over yet: go and spawn its first reflected ray
-                }
-                if (!have_ret) {  // the mirror ray (perfect_mirror.rs:18-27)
+                    d = out_dir;
                     depth += 1;
                     tmin = (float)RT_VERY_SMALL_NUMBER;
                     org_shape = shape;
@@ -182,7 +188,15 @@ RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t 
                                  ? (float)st
                                  : __builtin_inff();
                     counts.secondary += 1;
-                    continue;
+                    return false;
+                } else {
+                    top += 1;
+                    TreeFrame &f = frames[top];
+                    f.p = p; f.n = n; f.incoming = normalize(d);
+                    f.acc = ColorF{0.0f, 0.0f, 0.0f};
+                    f.k = 0; f.samples = sh.samples; f.alpha = sh.roughness;
+                    f.shape = shape; f.tri = gtri; f.depth = depth;
+                    deliver = false;  // nothing to hand over yet: go and spawn its first reflected ray
                 }
             } else {  // null.rs:7-9
                 ret = ColorF{1.0f, 0.0f, 1.0f};
@@ -191,7 +205,10 @@ RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t 
         // ---- a colour came back: hand it to the GGX hit that waits for it, or finish
         for (;;) {
             if (deliver) {
-                if (top < 0) return ret;
+                if (top < 0) {
+                    out = ret;
+                    return true;
+                }
                 TreeFrame &w = frames[top];
                 w.acc.r += ret.r; w.acc.g += ret.g; w.acc.b += ret.b;  // ggx_mirror.rs:89
                 w.k += 1;
@@ -221,27 +238,38 @@ RT_HD ColorF tree_sample(const RtSceneView &S, Stack &stk, D3 o, D3 d, uint64_t 
                          ? (float)st
                          : __builtin_inff();
             counts.secondary += 1;
-            break;
+            return false;
         }
+    }
+};
+
+// Where a finished sample's colour and ids go (k_resolve sums the colour slots).  Of the per-sample ids only the camera
+// ray's hit is defined for a tree.
+RT_HD void tree_store(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, uint32_t ls, const ColorF &c,
+                      int32_t primary_shape, int32_t primary_tri) {
+    write_color(Q, (int32_t)ls, c.r, c.g, c.b);
+    if (ids.primary_shape || ids.primary_tri || ids.final_shape || ids.final_tri || ids.bounces) {
+        const size_t gs = global_sample(B, ls);
+        if (ids.primary_shape) ids.primary_shape[gs] = primary_shape;
+        if (ids.primary_tri) ids.primary_tri[gs] = tri_file_index(S, primary_tri);
+        if (ids.final_shape) ids.final_shape[gs] = -1;
+        if (ids.final_tri) ids.final_tri[gs] = -1;
+        if (ids.bounces) ids.bounces[gs] = 0;
     }
 }
 
-// One local sample of a batch: camera ray, tree, colour into the sample's slot (k_resolve sums the slots).
+// One local sample of a batch, start to finish: camera ray, tree, colour into the sample's slot.
 template <class Stack, bool FAST>
 RT_HD void tree_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, const RtIdOut &ids, uint32_t ls, Stack &stk,
                      TreeCounts &counts) {
     D3 o, d;
     if (!sample_camera_ray(S, B, ls, o, d)) return;
-    const size_t gs = global_sample(B, ls);
-    int32_t ps, pt;
+    TreeWalk walk;
+    walk.begin(o, d, frame_sample(B, ls));
     bool ok = true;
-    const ColorF c = tree_sample<Stack, FAST>(S, stk, o, d, frame_sample(B, ls), B.seed, ps, pt, counts, ok);
+    ColorF c;
+    while (!walk.template step<Stack, FAST>(S, stk, B.seed, counts, ok, c)) {
+    }
     if (!ok) *Q.overflow = 1;
-    write_color(Q, (int32_t)ls, c.r, c.g, c.b);
-    // of the per-sample ids only the camera ray's hit is defined for a tree
-    if (ids.primary_shape) ids.primary_shape[gs] = ps;
-    if (ids.primary_tri) ids.primary_tri[gs] = tri_file_index(S, pt);
-    if (ids.final_shape) ids.final_shape[gs] = -1;
-    if (ids.final_tri) ids.final_tri[gs] = -1;
-    if (ids.bounces) ids.bounces[gs] = 0;
+    tree_store(S, Q, B, ids, ls, c, walk.primary_shape, walk.primary_tri);
 }

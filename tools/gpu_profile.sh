@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: kernel traces + the PMC passes over the benchmark command itself.
-# Usage: tools/gpu_profile.sh <tag> [workload] [mode]
+# Usage: tools/gpu_profile.sh <tag>_<workload> [workload] [mode]      (e.g. r03_bunny bunny)
 #   trace       rocprofv3 --kernel-trace --stats of the default command (frames in flight: kernels overlap)
 #   trace_solo  the same with --flights 1: every kernel alone on the GPU; these are the durations the
 #               bench line's roofline is computed from, and the counter passes run the same way
@@ -10,7 +10,7 @@ TAG=${1:-r02}; WL=${2:-bunny}; MODE=${3:-fast}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="bench.py --no-cpu-baseline --steps 20 --warmup 3 --workload $WL --mode $MODE"
+BENCH="bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3 --workload $WL --mode $MODE"
 SOLO="$BENCH --flights 1"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH > $OUT/trace.txt 2>&1 || { tail -5 $OUT/trace.txt; exit 1; }
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_solo -- python3 $SOLO > $OUT/trace_solo.txt 2>&1 || { tail -5 $OUT/trace_solo.txt; exit 1; }
@@ -42,7 +42,7 @@ cur.update(new)
 json.dump(cur, open("profiles/pmc_traffic.json", "w"), indent=1)
 PY
 cp profiles/pmc_traffic.json $OUT/pmc_traffic_merged.json
-timeout -k 10 300 python3 $BENCH > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 --workload $WL --mode $MODE > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
 # keep only the small files: the raw per-dispatch CSVs are large
 find $OUT -name "*_counter_collection.csv" -size +8M -delete
