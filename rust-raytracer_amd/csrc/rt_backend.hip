@@ -1569,7 +1569,9 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
         const uint32_t slots = std::min(batch_slots, n_slots - slot0);
         RtBatch B{};
-        B.tile_list = static_memory ? nullptr : be->tile_list;
+        // (a render that owns every tile needs no list: slot k is tile k, and every wave is spared a fetch that its
+        // first arithmetic would have had to wait for)
+        B.tile_list = static_memory || parts <= 1 ? nullptr : be->tile_list;
         B.tile_place = !static_memory && !be->tile_place_host.empty() ? be->tile_list + be->tile_list_host.size() : nullptr;
         B.slot0 = slot0;
         B.n_pixels = slots * tw * th;

@@ -125,8 +125,9 @@ struct TreeFrame {  // a GGX hit waiting for its reflected rays (ggx_mirror.rs:6
 // and of every sum is the order of the reference's recursion, whoever calls step() and however other samples' steps
 // are interleaved with it; `draws` counts the pairs drawn so far, `sample_index` is the frame-wide sample index (the
 // generator's counter).
+// (The stack of waiting GGX hits is the caller's array, not a member: an array that is indexed at run time lives in
+// scratch memory, and as a member it would take the whole walk -- current ray, depth, counters -- there with it.)
 struct TreeWalk {
-    TreeFrame frames[RT_TREE_MAX_DEPTH];
     D3 o, d;
     uint64_t sample_index;
     int32_t top, depth, org_shape, org_tri;
@@ -148,7 +149,7 @@ struct TreeWalk {
     }
 
     template <class Stack, bool FAST>
-    RT_HD bool step(const RtSceneView &S, Stack &stk, uint64_t seed, TreeCounts &counts, bool &ok, ColorF &out) {
+    RT_HD bool step(const RtSceneView &S, Stack &stk, TreeFrame *frames, uint64_t seed, TreeCounts &counts, bool &ok, ColorF &out) {
         const ColorF background = {S.background[0], S.background[1], S.background[2]};
         ColorF ret = background;
         // ---- trace the current ray and shade its hit: ends in a colour (ret) or in another ray
@@ -264,11 +265,12 @@ RT_HD void tree_body(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B,
                      TreeCounts &counts) {
     D3 o, d;
     if (!sample_camera_ray(S, B, ls, o, d)) return;
+    TreeFrame frames[RT_TREE_MAX_DEPTH];
     TreeWalk walk;
     walk.begin(o, d, frame_sample(B, ls));
     bool ok = true;
     ColorF c;
-    while (!walk.template step<Stack, FAST>(S, stk, B.seed, counts, ok, c)) {
+    while (!walk.template step<Stack, FAST>(S, stk, frames, B.seed, counts, ok, c)) {
     }
     if (!ok) *Q.overflow = 1;
     tree_store(S, Q, B, ids, ls, c, walk.primary_shape, walk.primary_tri);
