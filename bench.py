@@ -431,7 +431,7 @@ def make_comm(ctx, backend):
     one receive each, in one batch -- and the line says so: a scaling figure with a flag is worth more than none.
     RT_BENCH_EXCHANGE=torch forces the fallback."""
     rt, torch, dist = ctx.rt, ctx.torch, ctx.dist
-    ctx.comm, ctx.exchange, ctx.rccl_version = None, "gloo" if ctx.staged else "library", None
+    ctx.comm, ctx.exchange, ctx.rccl_version, ctx.exchange_note = None, "gloo" if ctx.staged else "library", None, None
     if ctx.staged:
         return
     failed = 0
@@ -442,14 +442,32 @@ def make_comm(ctx, backend):
         ids = [rt.Comm.make_id() if ctx.rank == 0 else None]
     except rt.RtError as e:
         ids, failed = [None], 1
+        ctx.exchange_note = f"rt_comm_id: {e}"
         print(f"[bench rank {ctx.rank}] rt_comm_id failed: {e}", file=sys.stderr)
     dist.broadcast_object_list(ids, src=0)
     if ids[0] is not None and not failed:
-        try:
-            ctx.comm = rt.Comm(backend, ids[0], ctx.rank, ctx.world)
-        except rt.RtError as e:
+        # ncclCommInitRank on a thread of its own with a limit: a bootstrap that never returns (it has only ever
+        # run with one device) must end in the flagged fallback, not in a run without a line
+        import threading
+        box = {}
+
+        def create():
+            try:
+                box["comm"] = rt.Comm(backend, ids[0], ctx.rank, ctx.world)
+            except rt.RtError as e:
+                box["error"] = e
+
+        limit = float(os.environ.get("RT_BENCH_COMM_TIMEOUT", "90"))
+        worker = threading.Thread(target=create, daemon=True)
+        worker.start()
+        worker.join(limit)
+        if "comm" in box:
+            ctx.comm = box["comm"]
+        else:
             failed = 1
-            print(f"[bench rank {ctx.rank}] rt_comm_create failed: {e}", file=sys.stderr)
+            why = box.get("error", f"no answer within {limit:.0f} s")
+            ctx.exchange_note = f"rt_comm_create: {why}"
+            print(f"[bench rank {ctx.rank}] rt_comm_create failed: {why}", file=sys.stderr)
     else:
         failed = 1
     agreed = torch.tensor([failed], dtype=torch.int32, device="cuda")
@@ -566,7 +584,7 @@ def main():
     if multi:
         make_comm(ctx, run.backends[0])
     else:
-        ctx.comm, ctx.exchange, ctx.rccl_version = None, "none (one GPU)", None
+        ctx.comm, ctx.exchange, ctx.rccl_version, ctx.exchange_note = None, "none (one GPU)", None, None
 
     # Warm-up frames are rendered with the backend's full statistics (an event pair around every
     # kernel, counters read back, the host waits for each frame, so every kernel runs alone on the
@@ -793,6 +811,7 @@ def main():
             "data": "synthetic",
             "exchange": ctx.exchange,
             "rccl_version": ctx.rccl_version,
+            "exchange_note": ctx.exchange_note or ("another rank's communicator failed" if ctx.exchange == "torch-fallback" else None),
             "config": {"workload": run.desc, "traversal": args.mode,
                        "mesh": "file found on this machine (scenes/models/bunny.obj)" if real_mesh and args.workload.startswith("bunny") else
                                "procedural stand-in" if args.workload.startswith("bunny") else "none",

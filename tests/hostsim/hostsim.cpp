@@ -454,8 +454,31 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
         const D3 lp = d3(S.lights[S.point_lights[light]].position);
         rays.push_back(R{p, lp - p, 1e-6f, 1.0f, st.shape, st.tri, true, i, j});
     }
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<int32_t> vn, vt, un, ut;
+    // level of every node inside its own tree (the header node of a tree is level 0)
+    std::vector<uint8_t> level(hs.flat.nodes.size(), 255);
+    {
+        std::vector<int32_t> roots{S.tlas_root};
+        for (size_t k = 0; k < hs.flat.tprims.size(); ++k)
+            if (hs.flat.tprims[k].type == RT_SHAPE_MESH ||
+                (hs.flat.tprims[k].type == RT_SHAPE_INSTANCE && hs.flat.tprims[k].proto_type == RT_SHAPE_MESH))
+                roots.push_back(hs.flat.tprims[k].blas_root);
+        std::vector<std::pair<int32_t, int>> todo;
+        for (int32_t r : roots) {
+            todo.emplace_back(r, 0);
+            while (!todo.empty()) {
+                const auto [ref, lv] = todo.back();
+                todo.pop_back();
+                if (ref < 0) continue;
+                const size_t k = (size_t)ref / sizeof(RtNode);
+                if (level[k] != 255) continue;
+                level[k] = (uint8_t)std::min(lv, 254);
+                todo.emplace_back(hs.flat.nodes[k].left, lv + 1);
+                todo.emplace_back(hs.flat.nodes[k].right, lv + 1);
+            }
+        }
+    }
     // RT_WAVE_DUMP=<file>: one record of six uint32 per wave (union nodes, longest lane's nodes, union
     // triangles, longest lane's triangles, pixel of the first ray)
     FILE *dump = std::getenv("RT_WAVE_DUMP") ? std::fopen(std::getenv("RT_WAVE_DUMP"), "wb") : nullptr;
@@ -480,12 +503,17 @@ extern "C" int hostsim_wave_union(const RtScene *scene, const RtRenderArgs *args
         std::sort(ut.begin(), ut.end()); ut.erase(std::unique(ut.begin(), ut.end()), ut.end());
         acc[0] += 1; acc[1] += (double)un.size(); acc[2] += (double)maxn; acc[3] += (double)sumn / 64.0;
         acc[4] += (double)ut.size(); acc[5] += (double)maxt; acc[6] += (double)sumt / 64.0;
+        for (int32_t ref : un) {
+            const uint8_t lv = level[(size_t)ref / sizeof(RtNode)];
+            acc[7] += lv < 6 ? 1.0 : 0.0;
+            acc[8] += lv < 8 ? 1.0 : 0.0;
+        }
         if (dump) {
             const uint32_t rec[6] = {(uint32_t)un.size(), (uint32_t)maxn, (uint32_t)ut.size(), (uint32_t)maxt, rays[w0].i, rays[w0].j};
             std::fwrite(rec, sizeof(rec), 1, dump);
         }
     }
     if (dump) std::fclose(dump);
-    for (int k = 0; k < 7; ++k) out[k] = acc[k];
+    for (int k = 0; k < 9; ++k) out[k] = acc[k];
     return 0;
 }

@@ -268,6 +268,44 @@ def test_render_multi_in_one_process(rt, scene_path, n, weight):
         b.close()
 
 
+def test_render_multi_is_timed(rt, scene_path):
+    """What rt-cli --gpus N and the Rust crate's render(.., gpus) call, with a number: the bunny frame at
+    1000x1000, 9 rays per pixel, through rt_render_multi with 1, 2 and 4 backends (all on this one device, so
+    the parts share a GPU and the gather is a device-local RCCL send / receive) into page-locked memory.  The
+    frame must be the unsplit render; the time per frame is printed and only bounded loosely (a frame split
+    over backends of ONE device cannot be faster than the whole frame; it must not be several times slower)."""
+    import importlib
+    import time
+
+    importlib.import_module("scenes.gen_scenes").ensure_models()
+    scene = rt.parse_scene_file(scene_path("bunny"), image_width=1000, image_height=1000, recursion_depth=6)
+    pinned = rt.HostBuffer((1000, 1000, 3))
+    whole, ms = None, {}
+    for n in (1, 2, 4):
+        backends = [rt.Backend(0) for _ in range(n)]
+        devs = [b.upload(scene) for b in backends]
+        if whole is None:
+            whole = devs[0].render(3, want_stats=False)[0].pixels.copy()
+        a = devs[0].render_args(3, tile=(40, 40))
+        multi = rt.Multi(devs)
+        for _ in range(5):
+            multi.render(a, out=pinned.array, want_stats=False)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            multi.render(a, out=pinned.array, want_stats=False)
+        ms[n] = (time.perf_counter() - t0) / 20 * 1e3
+        assert np.array_equal(pinned.array, whole)
+        multi.close()
+        for d in devs:
+            d.close()
+        for b in backends:
+            b.close()
+    pinned.close()
+    print("rt_render_multi, bunny 1000x1000 rpp9, blocking frames into page-locked memory, backends on one device: "
+          + ", ".join(f"{n}: {ms[n]:.3f} ms" for n in ms))
+    assert ms[1] < 3.0 and ms[4] < 4.0 * ms[1] + 1.0
+
+
 def test_comm_gather_with_one_rank(rt, backend, scene_path):
     """rt_comm_*: the communicator of a one-process-per-GPU launch with a single rank -- rank 0 sends
     its tiles to itself through RCCL and un-tiles them; what bench.py --gpus N does on every rank."""

@@ -34,13 +34,14 @@ def main():
     a.sqrt_rays_per_pixel = n
     a.tile_w = a.tile_h = tile
     for light in range(-1, scene.n_point_lights):
-        out = np.zeros(7, np.float64)
+        out = np.zeros(9, np.float64)
         rc = L.hostsim_wave_union(C.cast(scene.ptr, C.c_void_p), C.byref(a), light, out.ctypes.data)
         assert rc == 0
         w = max(out[0], 1)
         print(f"{'camera rays' if light < 0 else f'shadow rays, light {light}'}: {int(out[0])} waves; nodes per wave: union {out[1] / w:.1f}, "
               f"longest lane {out[2] / w:.1f}, mean lane {out[3] / w:.1f}; triangles per wave: union {out[4] / w:.1f}, "
-              f"longest lane {out[5] / w:.1f}, mean lane {out[6] / w:.1f}")
+              f"longest lane {out[5] / w:.1f}, mean lane {out[6] / w:.1f}; of the union's nodes, in levels 0-5 of their tree "
+              f"{out[7] / w:.1f}, in levels 0-7 {out[8] / w:.1f}")
 
 
 if __name__ == "__main__":
