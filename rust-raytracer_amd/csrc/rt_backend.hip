@@ -730,21 +730,33 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
 // per-lane kernel above.  Instrumented frames, per-lane -> packets: cornell_room 0.996 -> 0.952 ms (delivered,
 // four in flight: 0.746 -> 0.702), the same room with floor and back wall mirrors 2.04 -> 1.92, every wall a
 // mirror 4.38 -> 4.33, the bunny scene with the large bunny and the ground as mirrors 4.78 -> 3.24.
-// The grid is one resident set of waves striding over the queue; with a block per packet (35 156 of them) the
-// delivered cornell_room frame takes 1.0 ms, because every block then ends with its own adds to the counters.
+// With statistics the grid is one resident set of waves striding over the queue, each handing its ray counts to the
+// batch's counters once at the end (with a block per packet the delivered cornell_room frame took 1.0 ms, because
+// every block then ended with its own adds to those counters).  A frame without statistics needs no counts:
+// `tally_on` = 0, and the grid is a wave per packet, which the hardware deals out as waves finish -- mirror
+// chains differ in length (22 616 packets at bounce 1, 2909 at bounce 2, 42 at bounce 6 in cornell_room) and a fixed
+// deal waits for its unluckiest wave (one blocking frame 0.900 -> 0.858 ms).
 struct BouncePacketKernargs {
     RtSceneView S;
     RtBuffers Q;
     RtBatch B;
     RtIdOut ids;
     uint32_t n_samples;
+    uint32_t tally_on;
 };
 typedef const __attribute__((address_space(4))) BouncePacketKernargs *BouncePacketKernargsPtr;
+// Waves per SIMD: the stage behind a mirror ray's hit is a chain of dependent loads with f64 arithmetic in between,
+// and at the 72 registers of 7 waves it keeps 172 bytes per lane in scratch memory, every reload one more round trip
+// in that chain.  At 5 waves (96 registers, 24 bytes) a packet's bounce is shorter by more than the two waves are
+// worth: cornell_room delivered 0.577 ms at 7, 0.560 at 6, 0.549 at 5, 0.553 at 4 (117 registers, no scratch).
 #ifndef RT_BOUNCE_PACKET_WAVES
-#define RT_BOUNCE_PACKET_WAVES 7
+#define RT_BOUNCE_PACKET_WAVES 5
+#endif
+#ifndef RT_BOUNCE_PACKET_RESIDENT
+#define RT_BOUNCE_PACKET_RESIDENT RT_BOUNCE_PACKET_WAVES  // waves per SIMD that the kernel's grid asks for
 #endif
 __global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_PACKET_WAVES, RT_BOUNCE_PACKET_WAVES)))
-k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples) {
+k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples, uint32_t tally_on) {
     extern __shared__ int32_t lds[];
     const BouncePacketKernargsPtr args = (BouncePacketKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     int rows;
@@ -773,9 +785,12 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
         if (first >= queued) continue;
         const uint32_t idx0 = chunk * RT_LIT_CHUNK + first + threadIdx.x;
         bool going = first + threadIdx.x < queued;
-        if (threadIdx.x == 0u) tally[0] += min(queued - first, (uint32_t)RT_PACKET_BLOCK);  // rays of bounce 1
+        if (tally_on != 0u && threadIdx.x == 0u) tally[0] += min(queued - first, (uint32_t)RT_PACKET_BLOCK);  // rays of bounce 1
         for (int b = 1; __any(going); ++b) {
             FastTrav st[1];
+#ifdef RT_WAVE_TIMELINE
+            const unsigned long long bounce_t0 = wall_clock64();
+#endif
             {
                 const BouncePacketKernargs &K = fresh(args);
                 const uint32_t idx = opaque(idx0);
@@ -797,6 +812,10 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
                 st[0].org_tri = org_tri;
             }
             ok = packet_traverse<false, 1>(S, st, closest_tmin(1), lds, rows - 1) && ok;  // (the walk's fields of S stay in registers)
+#ifdef RT_WAVE_TIMELINE
+            const unsigned long long bounce_t1 = wall_clock64();
+            if (b <= 6) wave_log(2u * n_packets + (blk * 6u + (uint32_t)(b - 1)) * 2u, bounce_t0);
+#endif
             const BouncePacketKernargs &L = fresh(args);
             const uint32_t idx = opaque(idx0);
             MirrorTmp tmp;
@@ -811,7 +830,7 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
             going = act == RT_ACT_MIRROR;
             if (going) queue_write_ray(L.Q, which, idx, tmp);
             const unsigned long long on = __ballot(going);
-            if (on != 0ull && threadIdx.x == 0u) tally[b & 31] += (uint32_t)__popcll(on);  // rays of bounce b + 1
+            if (tally_on != 0u && on != 0ull && threadIdx.x == 0u) tally[b & 31] += (uint32_t)__popcll(on);  // rays of bounce b + 1
             unsigned long long todo = __ballot(act == RT_ACT_LIT);
             const uint32_t chunk = act == RT_ACT_LIT ? (uint32_t)sample / RT_LIT_CHUNK : ~0u;
             while (todo != 0ull) {
@@ -821,11 +840,14 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
                 wave_list_lit(L.Q, L.B.direct_lit != 0u, same, chunk == of, of, (uint32_t)sample);
                 todo &= ~same;
             }
+#ifdef RT_WAVE_TIMELINE
+            if (b <= 6) wave_log(2u * n_packets + (blk * 6u + (uint32_t)(b - 1)) * 2u + 1u, bounce_t1);
+#endif
         }
     }
     if (!ok) *fresh(args).Q.overflow = 1;
     __syncthreads();
-    if (threadIdx.x < 32u && tally[threadIdx.x] != 0u && RT_CNT_RAYS0 + threadIdx.x + 1 < RT_CNT_LIT)
+    if (tally_on != 0u && threadIdx.x < 32u && tally[threadIdx.x] != 0u && RT_CNT_RAYS0 + threadIdx.x + 1 < RT_CNT_LIT)
         atomicAdd(&fresh(args).Q.counters[RT_CNT_RAYS0 + threadIdx.x + 1], tally[threadIdx.x]);
 }
 
@@ -1643,8 +1665,11 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (bounce > 0 && fuse_bounce) {  // one launch follows the rays of bounce 1 through all later bounces
                 if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
                 if (use_packets) {  // one resident set of one-wave blocks
-                    const uint32_t gp = std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_WAVES);
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, n_samples);
+                    // With statistics: one resident set of waves striding over the packets, which hand their ray
+                    // counts to the batch's counters once each.  Without: a wave per packet, dealt by the hardware
+                    // as waves finish (mirror chains differ in length; a fixed deal waits for its unluckiest wave).
+                    const uint32_t gp = stats ? std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : packet_grid;
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u);
                 } else {
                     const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
                     hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);

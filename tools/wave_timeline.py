@@ -61,7 +61,7 @@ def main():
     a = dev.render_args(n, tile=(tile, tile), part=(part, parts))
     _, owned, stride = dev.partition_info(a)
     packets = -(-owned * tile * tile * n * n // 64)
-    log = torch.zeros(4 * packets + 64, dtype=torch.int64, device="cuda")
+    log = torch.zeros(28 * packets + 64, dtype=torch.int64, device="cuda")  # camera, shadow, 6 bounces x (walk, shade)
     fb = torch.zeros(W * H * 3 + tile * tile * 3 * 700, dtype=torch.float32, device="cuda")
     L = rt.lib()
     L.rt_debug_wave_log.argtypes = [C.c_void_p]
@@ -84,6 +84,21 @@ def main():
     both0 = np.concatenate([cam[:, 0], sh[:, 0]])
     both1 = np.concatenate([cam[:, 1], sh[:, 1]])
     describe("both kernels", both0, both1, 1024 * 8)
+    bo = v[4 * packets:28 * packets].reshape(packets, 6, 2, 2)  # [packet][bounce][walk / shade][start, end]
+    if (bo[:, :, 0, 1] > 0).any():
+        for b in range(6):
+            live = bo[:, b, 1, 1] > 0
+            if not live.any():
+                continue
+            walk = (bo[live, b, 0, 1] - bo[live, b, 0, 0]) * 10 / 1e3
+            shade = (bo[live, b, 1, 1] - bo[live, b, 1, 0]) * 10 / 1e3
+            print(f"mirror bounce {b + 1}: {int(live.sum())} packets; walk us: median {np.median(walk):.1f} p90 {np.percentile(walk, 90):.1f} "
+                  f"max {walk.max():.1f}; stage behind it: median {np.median(shade):.1f} p90 {np.percentile(shade, 90):.1f} max {shade.max():.1f}")
+        live = bo[:, :, 1, 1] > 0
+        t0 = np.where(live, bo[:, :, 0, 0], np.iinfo(np.int64).max).min(axis=1)
+        t1 = bo[:, :, 1, 1].max(axis=1)
+        has = live.any(axis=1)
+        describe("mirror bounces, per packet (first walk to last stage)", t0[has], t1[has], 1024 * 7)
     dev.close()
     be.close()
 
