@@ -209,9 +209,12 @@ enum {
     RT_RENDER_ROW_MAJOR_PIXELS = 2, /* work the pixels of a tile row by row instead of in small blocks */
     RT_RENDER_UNFUSED_SHADOWS = 4,  /* RT_MODE_FAST: one shadow-ray launch per light and a separate launch for the
                                        light sums, instead of one kernel for both */
-    RT_RENDER_UNFUSED_CAMERA = 8    /* RT_MODE_FAST: the camera rays and the stage that decides what happens to their
+    RT_RENDER_UNFUSED_CAMERA = 8,   /* RT_MODE_FAST: the camera rays and the stage that decides what happens to their
                                        hits as two launches (the hit records go through memory) instead of one, and
                                        likewise two launches per mirror bounce instead of one for all bounces */
+    RT_RENDER_TREE_DEPTH_FIRST = 16 /* scenes with a GGXMirror shader: one thread walks a sample's whole ray tree, depth
+                                       first, even where the tree could be traced level by level (RT_MODE_FAST in a
+                                       call that waits for its frame: rt_render, or any call that asks for statistics) */
 };
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is

@@ -101,17 +101,20 @@ double unit_from_bits(uint32_t hi, uint32_t lo) {
     return (double)(bits >> 11) / 9007199254740992.0;
 }
 
-// The numbers one camera sample's shading draws, in the order the reference's recursion asks for
-// them: pair k = Philox(counter (sample low, sample high, k, 1), key seed).  (antialias.rs's
-// offsets use counter (sample low, sample high, 0, 0).)
+// The numbers one camera sample's shading draws.  Every reflected ray that a GGX hit spawns has a PATH in
+// the sample's ray tree: the camera ray's is 0, the k-th ray (k = 0, 1, ...) spawned at a hit that a ray of
+// path P found has path (P << 8) + k + 1 (64 bits, wrapping: beyond eight rough bounces the oldest ones drop
+// out of the number); a perfect mirror passes its ray's path on unchanged.  The pair that shapes a ray is
+// Philox(counter (sample low, sample high, path low, path high), key seed).  A path is never 0, so these
+// counters never meet antialias.rs's (sample low, sample high, 0, 0).  Keyed this way a ray's numbers do not
+// depend on what any other ray of the tree hit, so an implementation may trace a tree in any order
+// (the reference's recursion is depth first; rand::thread_rng() makes its order unobservable anyway).
 struct SampleStream {
     uint64_t sample = 0, seed = 0;
-    uint32_t pairs_drawn = 0;
-    void next_pair(double &u1, double &u2) {
-        Philox g{{(uint32_t)(sample & 0xffffffffull), (uint32_t)(sample >> 32), pairs_drawn, 1u},
+    void pair_for(uint64_t path, double &u1, double &u2) const {
+        Philox g{{(uint32_t)(sample & 0xffffffffull), (uint32_t)(sample >> 32), (uint32_t)(path & 0xffffffffull), (uint32_t)(path >> 32)},
                  {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)}};
         g.run();
-        pairs_drawn += 1;
         u1 = unit_from_bits(g.ctr[0], g.ctr[1]);
         u2 = unit_from_bits(g.ctr[2], g.ctr[3]);
     }
@@ -259,6 +262,7 @@ struct Hit {
     Counters *counters = nullptr;
     SampleRecord *record = nullptr;
     struct SampleStream *stream = nullptr;  // uniform numbers of the GGX shader for this camera sample
+    uint64_t path = 0;                      // of this hit's ray in the sample's ray tree (see SampleStream)
 
     static Hit make(const Ray<Real> &ray, const Scene<Real> *scene) {  // Hit::new, :17-27
         Hit h;
@@ -698,6 +702,7 @@ Color apply_shader(const Hit<Real> &hit) {
         mirror_hit.counters = hit.counters;
         mirror_hit.record = hit.record;
         mirror_hit.stream = hit.stream;
+        mirror_hit.path = hit.path;
         if (hit.counters) hit.counters->rays[RC_SECONDARY]++;
         if (hit.record) hit.record->bounces = mirror_hit.depth;
         if (scene.bvh->closest_hit(mirror_hit)) return apply_shader(mirror_hit);
@@ -714,7 +719,8 @@ Color apply_shader(const Hit<Real> &hit) {
         for (uint32_t k = 0; k < sh.samples; ++k) {
             // sample_ggx, ggx_mirror.rs:29-51
             double u1d = 0.0, u2d = 0.0;
-            if (hit.stream) hit.stream->next_pair(u1d, u2d);
+            const uint64_t child_path = (hit.path << 8) + (uint64_t)k + 1ull;
+            if (hit.stream) hit.stream->pair_for(child_path, u1d, u2d);
             const Real u1 = (Real)u1d, u2 = (Real)u2d, alpha = (Real)sh.roughness;
             const Real phi = (Real)2.0 * (Real)3.14159265358979323846 * u1;
             const Real theta = std::atan(std::sqrt(alpha * alpha * u2 / ((Real)1.0 - u2)));
@@ -732,6 +738,7 @@ Color apply_shader(const Hit<Real> &hit) {
             mirror_hit.ray_class = RC_SECONDARY;
             mirror_hit.counters = hit.counters;
             mirror_hit.stream = hit.stream;
+            mirror_hit.path = child_path;
             if (hit.counters) hit.counters->rays[RC_SECONDARY]++;
             accumulated += scene.bvh->closest_hit(mirror_hit) ? apply_shader(mirror_hit) : scene.background;
         }

@@ -63,7 +63,12 @@
 #define RT_BLOCK 256
 #endif
 #define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
+#define RT_TREE_ROOM 6u   // ray trees level by level: nodes a level may have for every camera ray of its batch
 #define RT_PACKET_BLOCK 64
+// kernels that work through a chunk of RT_LIT_CHUNK samples per block
+#define RT_LIT_BLOCK RT_LIT_CHUNK
+#define RT_LIT_THREADS 256
+#define RT_LIT_ROUNDS (RT_LIT_BLOCK / RT_LIT_THREADS)
 
 // Work memory of rt_render_device_static: one array per device the library runs on, part of the
 // code object, so it exists from the moment the library is loaded on a device until the process ends
@@ -825,7 +830,10 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
                 D3 o, d;
                 sample = L.Q.q_sample[which][idx];
                 queue_read_ray(L.Q, which, idx, o, d);
-                act = shade_hit(L.S, L.Q, L.B, L.ids, b, sample, o, d, st[0].shape, st[0].tri, st[0].t, tmp);
+                // reflections in front of this ray: the round's number, or (a level of ray trees, whose rays start at
+                // different depths) what the ray started with plus the mirrors since
+                const int depth = L.Q.n_depth != nullptr ? L.Q.n_depth[idx] + b - 1 : b;
+                act = shade_hit(L.S, L.Q, L.B, L.ids, depth, sample, o, d, st[0].shape, st[0].tri, st[0].t, tmp);
             }
             going = act == RT_ACT_MIRROR;
             if (going) queue_write_ray(L.Q, which, idx, tmp);
@@ -874,6 +882,146 @@ __global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffe
     }
 }
 
+// ---- scenes with a GGX shader, ray trees traced LEVEL BY LEVEL (fast mode, in a call that may wait):
+// the rays of level L of all the batch's trees -- level 0 = the camera rays, level L + 1 = the reflected rays
+// that the GGX hits of level L spawn -- go through the fast mode's stages as if they were a batch's samples:
+// packet walk, the stage behind it (mirror chains included), shadow packets and light sums, colour into the
+// ray's slot of the level's colour array.  A ray whose chain ends on a GGX surface leaves the hit in its slot
+// (shade_hit's RT_ACT_GGX); the kernels below number the next level's rays (count -> scan -> link), make them
+// (spawn), and when the deepest level is done add the children's colours up into their parents, level by level
+// upwards, in the order of the reference's loop (ggx_mirror.rs:66-93).  Against the depth-first walk of one
+// lane per tree (k_render_tree) the rays of a level are coherent enough for packets, no lane waits for a
+// neighbour's deeper tree, and nothing lives in scratch memory.
+struct TreeLevelView {
+    uint32_t *off, *chunk_base, *parent;
+    uint32_t *base, *count;               // of the level that spawns
+    const uint64_t *root_in, *path_in;    // per node of the level that spawns (unused at level 0)
+    uint64_t *root_out, *path_out;        // per node of the level being made
+    int32_t *depth_out;
+};
+
+// One block per chunk of RT_LIT_CHUNK nodes: how many rays each node spawns (its shader's `samples` where its
+// chain ended on a GGX surface), the exclusive sums inside the chunk, the chunk's total.
+__global__ void __launch_bounds__(RT_LIT_THREADS) k_tree_count(RtSceneView S, RtBuffers Q, TreeLevelView T, uint32_t n_nodes) {
+    __shared__ uint32_t wave_sum[RT_LIT_THREADS / 64];
+    const uint32_t first = blockIdx.x * RT_LIT_CHUNK + threadIdx.x * RT_LIT_ROUNDS;  // RT_LIT_ROUNDS consecutive nodes per thread
+    uint32_t want[RT_LIT_ROUNDS], mine = 0;
+    for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
+        const uint32_t node = first + r;
+        const int32_t mark = node < n_nodes ? Q.g_mark[node] : -1;
+        want[r] = mark >= 0 ? S.shaders[(uint32_t)mark >> 8].samples : 0u;
+        mine += want[r];
+    }
+    uint32_t incl = mine;  // inclusive scan over the wave, then over the block's waves
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)(threadIdx.x & 63u) >= d) incl += v;
+    }
+    if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < RT_LIT_THREADS / 64; ++w) {
+        if (w < (threadIdx.x >> 6)) before += wave_sum[w];
+        total += wave_sum[w];
+    }
+    uint32_t run = before + incl - mine;
+    for (uint32_t r = 0; r < RT_LIT_ROUNDS; ++r) {
+        if (first + r < n_nodes) T.off[first + r] = run;
+        run += want[r];
+    }
+    if (threadIdx.x == 0) T.chunk_base[blockIdx.x] = total;
+}
+
+// One block: chunk_base[0 .. n_chunks) -> exclusive sums in place, the total behind them.
+__global__ void __launch_bounds__(RT_LIT_THREADS) k_tree_scan(TreeLevelView T, uint32_t n_chunks) {
+    __shared__ uint32_t part[RT_LIT_THREADS];
+    const uint32_t per = (n_chunks + RT_LIT_THREADS - 1u) / RT_LIT_THREADS;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_chunks);
+    uint32_t acc = 0;
+    for (uint32_t b = lo; b < hi; ++b) acc += T.chunk_base[b];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < RT_LIT_THREADS; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - acc;
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = T.chunk_base[b];
+        T.chunk_base[b] = run;
+        run += c;
+    }
+    if (threadIdx.x == RT_LIT_THREADS - 1) T.chunk_base[n_chunks] = part[RT_LIT_THREADS - 1];
+}
+
+// One thread per node of the level that spawns: where its children start in the next level and how many they are
+// (kept per level for the sums on the way back up), and each child's parent.  `room`: nodes the next level can hold;
+// the host has checked the total against it before this launch.
+__global__ void __launch_bounds__(RT_BLOCK) k_tree_link(RtSceneView S, RtBuffers Q, TreeLevelView T, uint32_t n_nodes) {
+    const uint32_t node = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (node >= n_nodes) return;
+    const int32_t mark = Q.g_mark[node];
+    const uint32_t want = mark >= 0 ? S.shaders[(uint32_t)mark >> 8].samples : 0u;
+    const uint32_t base = T.chunk_base[node / RT_LIT_CHUNK] + T.off[node];
+    T.base[node] = base;
+    T.count[node] = want;
+    for (uint32_t k = 0; k < want; ++k) T.parent[base + k] = node;
+}
+
+// One thread per ray of the level being made: the k-th reflected ray of its parent's GGX hit (ggx_mirror.rs:66-76),
+// into slot = its own number of mirror-ray queue 1, where k_bounces_packet takes a level's rays from.
+__global__ void __launch_bounds__(RT_BLOCK) k_tree_spawn(RtSceneView S, RtBuffers Q, RtBatch B, TreeLevelView T, uint32_t level, uint32_t n_children) {
+    const uint32_t c = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (c >= n_children) return;
+    const uint32_t parent = T.parent[c], k = c - T.base[parent];
+    const int32_t mark = Q.g_mark[parent];
+    const RtShader &sh = S.shaders[(uint32_t)mark >> 8];
+    const D3 p = D3{RT_STREAM_LD(Q.g_p[0][parent]), RT_STREAM_LD(Q.g_p[1][parent]), RT_STREAM_LD(Q.g_p[2][parent])};
+    const D3 n = D3{RT_STREAM_LD(Q.g_n[0][parent]), RT_STREAM_LD(Q.g_n[1][parent]), RT_STREAM_LD(Q.g_n[2][parent])};
+    const D3 incoming = D3{RT_STREAM_LD(Q.g_in[0][parent]), RT_STREAM_LD(Q.g_in[1][parent]), RT_STREAM_LD(Q.g_in[2][parent])};
+    const int32_t shape = Q.g_shape[parent], tri = Q.g_tri[parent];
+    const uint64_t root = level == 0u ? frame_sample(B, parent) : T.root_in[parent];
+    const uint64_t path = tree_child_path(level == 0u ? 0ull : T.path_in[parent], k);
+    MirrorTmp tmp;
+    tmp.p = p;
+    tmp.d = ggx_child_direction(n, incoming, sh.roughness, root, path, B.seed);
+    tmp.sample = (int32_t)c;
+    tmp.shape = shape;
+    tmp.tri = tri;
+    double st;
+    tmp.self_t = self_hit_f64(S, shape, tmp.p, tmp.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(n, tmp.d) > 0.0, false, st)
+                     ? (float)st
+                     : __builtin_inff();
+    queue_write_ray(Q, 1, c, tmp);
+    T.root_out[c] = root;
+    T.path_out[c] = path;
+    T.depth_out[c] = (mark & 0xff) + 1;
+    // the queue's stretches (RtBuffers::mirror_counts): a level's rays fill them without gaps
+    if (c % RT_LIT_CHUNK == 0u) Q.mirror_counts[c / RT_LIT_CHUNK] = min(n_children - c, (uint32_t)RT_LIT_CHUNK);
+}
+
+// One thread per node of a level whose children are done: ggx_mirror.rs:89-93, the children's colours added up in
+// their order, divided by their number.
+__global__ void __launch_bounds__(RT_BLOCK) k_tree_gather(const uint32_t *base, const uint32_t *count, const float *child_color, float *color, uint32_t n_nodes) {
+    const uint32_t node = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (node >= n_nodes) return;
+    const uint32_t n = count[node];
+    if (n == 0u) return;
+    const float *c = child_color + (size_t)base[node] * 3;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < n; ++k) {
+        r += c[3 * k + 0];
+        g += c[3 * k + 1];
+        b += c[3 * k + 2];
+    }
+    const float div = (float)n;
+    color[(size_t)node * 3 + 0] = r / div;
+    color[(size_t)node * 3 + 1] = g / div;
+    color[(size_t)node * 3 + 2] = b / div;
+}
+
 // ---- compaction of the lit table into a list of sample indices, in sample order: the shade stage
 // has counted the lit hits of every chunk of RT_LIT_CHUNK samples; an exclusive scan of the chunk counts
 // and a scatter follow.  Large chunks keep the single-block scan in the middle short: it is pure
@@ -886,9 +1034,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffe
 // leave that many, and these small kernels -- which every frame waits for -- sat in the queue
 // for hundreds of microseconds.
 
-#define RT_LIT_BLOCK RT_LIT_CHUNK
-#define RT_LIT_THREADS 256
-#define RT_LIT_ROUNDS (RT_LIT_BLOCK / RT_LIT_THREADS)
 
 // One block: counters[RT_CNT_LIT] = sum of block_counts[0..n_blocks), for the statistics of a batch whose lit
 // hits were listed directly (nothing on the device needs the total then).
@@ -1244,6 +1389,45 @@ int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
     return RT_OK;
 }
 
+// The arrays of the level-by-level ray trees for `capacity` nodes per level and levels 0 .. `levels` - 1.
+int ensure_tree_buffers(RtBackend *be, uint32_t capacity, int levels) {
+    RtBackend::TreeLevels &t = be->tree;
+    if (t.capacity < capacity) {
+        free_all(t.allocs);
+        t = RtBackend::TreeLevels();
+        const size_t cap = capacity;
+        for (int k = 0; k < 3; ++k) {
+            if (int rc = alloc_into(t.allocs, &t.g_p[k], cap)) return rc;
+            if (int rc = alloc_into(t.allocs, &t.g_n[k], cap)) return rc;
+            if (int rc = alloc_into(t.allocs, &t.g_in[k], cap)) return rc;
+        }
+        if (int rc = alloc_into(t.allocs, &t.g_shape, cap)) return rc;
+        if (int rc = alloc_into(t.allocs, &t.g_tri, cap)) return rc;
+        if (int rc = alloc_into(t.allocs, &t.g_mark, cap)) return rc;
+        if (int rc = alloc_into(t.allocs, &t.off, cap)) return rc;
+        if (int rc = alloc_into(t.allocs, &t.chunk_base, cap / RT_LIT_CHUNK + 2)) return rc;
+        if (int rc = alloc_into(t.allocs, &t.parent, cap)) return rc;
+        for (int w = 0; w < 2; ++w) {
+            if (int rc = alloc_into(t.allocs, &t.root[w], cap)) return rc;
+            if (int rc = alloc_into(t.allocs, &t.path[w], cap)) return rc;
+            if (int rc = alloc_into(t.allocs, &t.depth[w], cap)) return rc;
+        }
+        t.capacity = capacity;
+    }
+    while ((int)t.base.size() < levels) {
+        float *color = nullptr;
+        uint32_t *base = nullptr, *count = nullptr;
+        if (!t.base.empty())  // (level 0's colours are the batch's)
+            if (int rc = alloc_into(t.allocs, &color, (size_t)t.capacity * 3)) return rc;
+        if (int rc = alloc_into(t.allocs, &base, t.capacity)) return rc;
+        if (int rc = alloc_into(t.allocs, &count, t.capacity)) return rc;
+        t.color.push_back(color);
+        t.base.push_back(base);
+        t.count.push_back(count);
+    }
+    return RT_OK;
+}
+
 uint32_t grid_for(uint64_t work) {
     const uint64_t blocks = (work + RT_BLOCK - 1) / RT_BLOCK;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, RT_MAX_GRID));
@@ -1505,8 +1689,20 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                                                      std::to_string((size_t)RT_STATIC_SCRATCH_BYTES) + ": use smaller tiles or fewer rays per pixel");
         slots_per_batch = fit;
     }
-    const uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
-    const uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
+    uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
+    uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
+    // Ray trees level by level (see k_tree_count): fast mode with all its fused kernels, in a call that may wait for
+    // the device between levels (it reads how many rays the next level has).  A level's rays lie in the batch
+    // buffers like a batch's samples, so a batch of camera rays is sized to leave room for levels that are larger
+    // than it: RT_TREE_ROOM times.  A level that still does not fit halves the batch (below).
+    const bool tree_levels = ds->has_ggx && args->mode == RT_MODE_FAST && !static_memory && (blocking || stats != nullptr) &&
+                             (args->flags & (RT_RENDER_TREE_DEPTH_FIRST | RT_RENDER_NO_PACKETS | RT_RENDER_UNFUSED_SHADOWS | RT_RENDER_UNFUSED_CAMERA)) == 0u &&
+                             ds->n_point_lights <= 32;
+    if (tree_levels) {
+        const uint32_t room_slots = (uint32_t)std::min<uint64_t>(slots_per_batch, (uint64_t)std::max<uint32_t>(n_slots, 1) * RT_TREE_ROOM);
+        batch_slots = std::min(std::max<uint32_t>(n_slots, 1), std::max<uint32_t>(1, room_slots / RT_TREE_ROOM));
+        capacity = (uint32_t)(std::max(room_slots, batch_slots) * tile_samples);
+    }
     int rc = RT_OK;
     if (static_memory) {
         size_t used = 0;
@@ -1520,6 +1716,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     } else if ((rc = ensure_buffers(be, capacity, ds->n_point_lights))) {
         return rc;
     }
+    if (tree_levels && (rc = ensure_tree_buffers(be, be->buf_capacity, 2))) return rc;
     RtBuffers Q = static_memory ? carved : be->buf;
     Q.lit_f32 = args->mode == RT_MODE_REFERENCE_ORDER ? 0u : 1u;
     const RtSceneView &S = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view : ds->view_fast;
@@ -1588,8 +1785,14 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (armed) be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
         }
     } dirty_guard{be, !static_memory};
-    for (uint32_t slot0 = 0; slot0 < n_slots; slot0 += batch_slots) {
-        const uint32_t slots = std::min(batch_slots, n_slots - slot0);
+    // ray trees level by level: tiles per batch (halved when a level outgrows the buffers), what the levels' own
+    // counters came to, and whether the batch at hand has fallen back to the depth-first kernel
+    uint32_t tree_slots = batch_slots;
+    uint64_t tree_secondary = 0, tree_lit = 0;
+    bool tree_depth_first = false;
+    for (uint32_t slot0 = 0, step = 0; slot0 < n_slots; slot0 += step) {
+        const uint32_t slots = std::min(tree_levels ? tree_slots : batch_slots, n_slots - slot0);
+        step = slots;
         RtBatch B{};
         // (a render that owns every tile needs no list: slot k is tile k, and every wave is spared a fetch that its
         // first arithmetic would have had to wait for)
@@ -1645,7 +1848,117 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
-        if (ds->has_ggx) {  // the ray-tree path replaces stages 1-5
+        if (tree_levels && !tree_depth_first) {
+            // ---- level 0: the camera rays; level L + 1: what the GGX hits of level L spawn (see k_tree_count)
+            RtBackend::TreeLevels &tl = be->tree;
+            const uint32_t room = Q.capacity;
+            uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
+                                       Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
+            for (int k = 0; k < 3; ++k) {
+                Q.g_p[k] = tl.g_p[k];
+                Q.g_n[k] = tl.g_n[k];
+                Q.g_in[k] = tl.g_in[k];
+            }
+            Q.g_shape = tl.g_shape; Q.g_tri = tl.g_tri; Q.g_mark = tl.g_mark;
+            std::vector<uint32_t> level_nodes;  // rays per level
+            bool too_large = false;
+            uint64_t batch_secondary = 0, batch_lit = 0;
+            uint32_t nodes = n_samples;
+            for (int level = 0;; ++level) {
+                // this level's rays through the stages
+                RtBuffers L = Q;
+                const uint32_t chunks = (nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
+                L.counters = sets[level & 1];
+                L.block_counts = L.counters + RT_CNT_SIZE;
+                L.mirror_counts = L.block_counts + chunks;
+                L.counters_next = sets[(level & 1) ^ 1];
+                L.color = level == 0 ? Q.color : tl.color[(size_t)level];
+                L.n_depth = level == 0 ? nullptr : tl.depth[level & 1];
+                const uint32_t grid_packets = (nodes + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+                const uint32_t grid_threads = (nodes + RT_BLOCK - 1) / RT_BLOCK;
+                uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, grid_threads / 256u));
+                while ((xcd_chunk & (xcd_chunk - 1u)) != 0u) xcd_chunk &= xcd_chunk - 1u;
+                const RtIdOut level_io = level == 0 ? io : RtIdOut{};
+                if (level == 0) {
+                    RT_HIP(hipMemsetAsync(L.counters, 0, ((size_t)RT_CNT_SIZE + 2u * chunks) * sizeof(uint32_t), stream));
+                } else {
+                    // (this level's counters were cleared before its rays were made: the spawn kernel has written the
+                    // queue's stretch lengths into them)
+                }
+                RT_HIP(hipMemsetAsync(Q.g_mark, 0xff, (size_t)nodes * sizeof(int32_t), stream));
+                if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                if (level == 0)
+                    hipLaunchKernelGGL(k_camera_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, L, B, level_io, nodes, xcd_chunk, 0u);
+                if (level > 0 || ds->has_mirror) {
+                    const uint32_t gp = stats ? std::min<uint32_t>(grid_packets, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : grid_packets;
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
+                }
+                tm.end();
+                if (ds->has_lit) {
+                    if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, L, chunks);
+                    if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                    hipLaunchKernelGGL(k_shadow_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, xcd_chunk);
+                    tm.end();
+                }
+                level_nodes.push_back(nodes);
+                // how many rays the GGX hits of this level spawn
+                if ((rc = ensure_tree_buffers(be, room, level + 2))) return rc;
+                TreeLevelView T{};
+                T.off = tl.off; T.chunk_base = tl.chunk_base; T.parent = tl.parent;
+                T.base = tl.base[(size_t)level]; T.count = tl.count[(size_t)level];
+                T.root_in = tl.root[level & 1]; T.path_in = tl.path[level & 1];
+                T.root_out = tl.root[(level & 1) ^ 1]; T.path_out = tl.path[(level & 1) ^ 1];
+                T.depth_out = tl.depth[(level & 1) ^ 1];
+                if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                hipLaunchKernelGGL(k_tree_count, dim3(chunks), dim3(RT_LIT_THREADS), 0, stream, S, L, T, nodes);
+                hipLaunchKernelGGL(k_tree_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, T, chunks);
+                tm.end();
+                uint32_t next_nodes = 0, level_counters[RT_CNT_SIZE];
+                RT_HIP(hipMemcpyAsync(&next_nodes, T.chunk_base + chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                if (stats) RT_HIP(hipMemcpyAsync(level_counters, L.counters, sizeof(level_counters), hipMemcpyDeviceToHost, stream));
+                RT_HIP(hipStreamSynchronize(stream));
+                if (stats) {
+                    for (int b = 1; b < 32; ++b) batch_secondary += level_counters[RT_CNT_RAYS0 + b];
+                    batch_lit += level_counters[RT_CNT_LIT];
+                }
+                if (next_nodes == 0u) break;
+                if (next_nodes > room) {
+                    too_large = true;
+                    break;
+                }
+                // the next level's rays
+                RtBuffers N = Q;
+                const uint32_t next_chunks = (next_nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
+                N.counters = sets[(level & 1) ^ 1];
+                N.block_counts = N.counters + RT_CNT_SIZE;
+                N.mirror_counts = N.block_counts + next_chunks;
+                RT_HIP(hipMemsetAsync(N.counters, 0, ((size_t)RT_CNT_SIZE + 2u * next_chunks) * sizeof(uint32_t), stream));
+                if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                hipLaunchKernelGGL(k_tree_link, dim3(grid_threads), dim3(RT_BLOCK), 0, stream, S, L, T, nodes);
+                hipLaunchKernelGGL(k_tree_spawn, dim3((next_nodes + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, S, N, B, T, (uint32_t)level, next_nodes);
+                tm.end();
+                nodes = next_nodes;
+            }
+            if (too_large) {
+                // A level has more rays than the buffers hold: the same tiles again in smaller batches (a ray's numbers
+                // do not depend on its batch), and a single tile that does not fit through the depth-first kernel.
+                be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
+                if (slots > 1) tree_slots = std::max(1u, slots / 2u);
+                else tree_depth_first = true;
+                step = 0;
+                continue;
+            }
+            // the children's colours into their parents, deepest level first
+            if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            for (int level = (int)level_nodes.size() - 2; level >= 0; --level)
+                hipLaunchKernelGGL(k_tree_gather, dim3((level_nodes[(size_t)level] + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream,
+                                   tl.base[(size_t)level], tl.count[(size_t)level], tl.color[(size_t)level + 1],
+                                   level == 0 ? Q.color : tl.color[(size_t)level], level_nodes[(size_t)level]);
+            tm.end();
+            tree_secondary += batch_secondary;
+            tree_lit += batch_lit;
+            be->counter_dirty[0] = be->counter_dirty[1] = ~0u;  // the levels took turns with both sets
+        } else if (ds->has_ggx) {  // one thread per ray tree, depth first: replaces stages 1-5
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
                 hipLaunchKernelGGL((k_render_tree<false>), dim3(full_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, n_samples);
@@ -1738,7 +2051,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         tm.end();
 
         if (wait_batches) {
-            if (stats) {  // counters must be read before the next batch clears them
+            if (stats && !(tree_levels && !tree_depth_first)) {  // counters must be read before the next batch clears them
                 const size_t at = host_counters.size();
                 host_counters.resize(at + RT_CNT_SIZE);
                 RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t),
@@ -1758,6 +2071,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                 args->progress(inside(0, slot0 + slots), inside(0, n_slots), args->progress_user);
             }
         }
+        tree_depth_first = false;  // (it was this batch's alone)
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess)  // a launch failed: which counters were zeroed is not known
         return rt::set_error(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1779,6 +2093,9 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             const uint64_t w_in = std::min(tw, W - x0), h_in = std::min(th, H - y0);
             stats->primary_rays += w_in * h_in * spp;
         }
+        stats->secondary_rays += tree_secondary;  // ray trees level by level: the levels' own counters
+        stats->shaded_hits += tree_lit;
+        if (!S.disable_shadows) stats->shadow_rays += tree_lit * ds->n_point_lights;
         for (size_t at = 0; at < host_counters.size(); at += RT_CNT_SIZE) {
             const uint32_t *c = host_counters.data() + at;
             if (ds->has_ggx) {

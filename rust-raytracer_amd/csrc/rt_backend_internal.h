@@ -47,6 +47,21 @@ struct RtBackend {
     uint32_t *sticky_host = nullptr;
     // device address of this device's static work array (rt_render_device_static), from hipGetSymbolAddress
     unsigned char *scratch = nullptr;
+    // Ray trees traced level by level (scenes with a GGXMirror shader): grown on demand, see ensure_tree_buffers
+    struct TreeLevels {
+        std::vector<void *> allocs;
+        uint32_t capacity = 0;
+        double *g_p[3] = {}, *g_n[3] = {}, *g_in[3] = {};
+        int32_t *g_shape = nullptr, *g_tri = nullptr, *g_mark = nullptr;
+        uint32_t *off = nullptr;         // [capacity] where a node's children start inside its chunk's run of children
+        uint32_t *chunk_base = nullptr;  // [chunks + 1] children per chunk of nodes, then their exclusive sums; last: all
+        uint32_t *parent = nullptr;      // [capacity] the node that each node of the NEXT level hangs under
+        uint64_t *root[2] = {}, *path[2] = {};  // [capacity] per node: its tree's frame-wide sample index, its ray's path
+        int32_t *depth[2] = {};          // [capacity] per node: reflections in front of its ray
+        // per level (level 0 is the batch's samples, whose colours are the batch's own colour array)
+        std::vector<float *> color;      // [3 * capacity]
+        std::vector<uint32_t *> base, count;  // [capacity] children of each node: where they start in the next level, how many
+    } tree;
     // tile list of the last partition
     int32_t *tile_list = nullptr;
     std::vector<int32_t> tile_list_host;

@@ -82,6 +82,16 @@ struct RtBuffers {
                              // c * RT_LIT_CHUNK on, block_counts[c] of them
     uint32_t capacity;       // samples a batch can hold
     uint32_t lit_f32;        // set per frame: the lit table's vectors are stored as f32 (fast mode), see lit_store_vec
+    // Ray trees traced level by level (scenes with a GGXMirror shader, rt_backend.hip): the rays of one level of all
+    // the batch's trees are the "samples" of a pass through the stages above, and a ray whose chain ends on a GGX
+    // surface leaves that hit here, in its own slot, for the pass that spawns the next level.  Null otherwise.
+    double *g_p[3];          // hit point
+    double *g_n[3];          // unit normal
+    double *g_in[3];         // normalised direction of the ray that hit (ggx_mirror.rs:62)
+    int32_t *g_shape;
+    int32_t *g_tri;
+    int32_t *g_mark;         // (shader index << 8) | depth of the hit; < 0: the slot's ray did not end on a GGX surface
+    const int32_t *n_depth;  // levels >= 1: the depth (reflections so far) of each slot's ray as it was spawned; null at level 0
 };
 
 #define RT_LIT_CHUNK 1024u
@@ -321,7 +331,7 @@ RT_HD void trace_closest_fast_body(const RtSceneView &S, const RtBuffers &Q, con
 }
 
 // ---- shade
-enum { RT_ACT_NONE = 0, RT_ACT_MIRROR = 1, RT_ACT_LIT = 2 };
+enum { RT_ACT_NONE = 0, RT_ACT_MIRROR = 1, RT_ACT_LIT = 2, RT_ACT_GGX = 3 };
 
 struct MirrorTmp {
     D3 p, d;  // origin and direction of the reflected ray
@@ -411,6 +421,22 @@ RT_HD int shade_hit(const RtSceneView &S, const RtBuffers &Q, const RtBatch &B, 
                          ? (float)st
                          : __builtin_inff();
         return RT_ACT_MIRROR;
+    }
+    case RT_SHADER_GGX_MIRROR: {  // ggx_mirror.rs:54-94, the part in front of the loop over the reflected rays
+        if (bounce >= S.recursion_depth || Q.g_mark == nullptr) {
+            write_color(Q, sample, S.background[0], S.background[1], S.background[2]);
+            return RT_ACT_NONE;
+        }
+        const D3 incoming = normalize(d);
+        for (int k = 0; k < 3; ++k) {
+            RT_STREAM_ST(Q.g_p[k][sample], k == 0 ? p.x : k == 1 ? p.y : p.z);
+            RT_STREAM_ST(Q.g_n[k][sample], k == 0 ? n.x : k == 1 ? n.y : n.z);
+            RT_STREAM_ST(Q.g_in[k][sample], k == 0 ? incoming.x : k == 1 ? incoming.y : incoming.z);
+        }
+        RT_STREAM_ST(Q.g_shape[sample], shape);
+        RT_STREAM_ST(Q.g_tri[sample], gtri);
+        RT_STREAM_ST(Q.g_mark[sample], (int32_t)(((uint32_t)S.shapes[shape].shader << 8) | (uint32_t)bounce));
+        return RT_ACT_GGX;
     }
     case RT_SHADER_NORMAL:  // normal.rs:10-16
         write_color(Q, sample, (1.0f + (float)n.x) / 2.0f, (1.0f + (float)n.y) / 2.0f, (1.0f + (float)n.z) / 2.0f);

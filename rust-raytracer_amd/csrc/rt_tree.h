@@ -10,11 +10,16 @@
 // is to produce the reference's image, sample by sample.
 //
 // Random numbers.  ggx_mirror.rs:33-34 draws two uniform numbers per reflected ray from
-// rand::thread_rng(), which the operating system seeds: no two reference runs agree.  Here the
-// k-th pair a sample draws (k counts in the order of the reference's recursion) is
-// Philox4x32-10(counter = (sample index low, high, k, 1), key = seed): u1 from output words
-// 0 and 1, u2 from words 2 and 3, 53 bits each.  (Word 3 of the counter is 0 for the sample
-// offsets of antialias.rs and 1 here, so the two streams never meet.)
+// rand::thread_rng(), which the operating system seeds: no two reference runs agree, and the order
+// in which its recursion draws cannot be observed.  Here a ray's pair is keyed by the ray's PATH in
+// its sample's tree: the camera ray has path 0; the k-th ray (k = 0, 1, ...) that a GGX hit spawns,
+// found by a ray of path P, has path (P << 8) + k + 1 (64 bits, wrapping: beyond eight rough bounces
+// the oldest drop out); a perfect mirror passes its path on.  The pair is Philox4x32-10(counter =
+// (sample index low, high, path low, path high), key = seed): u1 from output words 0 and 1, u2 from
+// words 2 and 3, 53 bits each.  (A path is never 0, the sample offsets of antialias.rs use counter
+// words (.., 0, 0): the two streams never meet.)  A ray's numbers thus do not depend on what any other
+// ray of the tree hit, and the tree may be traced depth first (this file) or level by level
+// (the wavefront path of rt_backend.hip) with the same result.
 #pragma once
 
 #include <math.h>
@@ -31,6 +36,11 @@ RT_HD void create_coordinate_system(const D3 &normal, D3 &tangent, D3 &bitangent
 }
 
 // GGXMirrorShader::sample_ggx, ggx_mirror.rs:29-51
+RT_HD uint64_t tree_child_path(uint64_t path, uint32_t k) { return (path << 8) + (uint64_t)k + 1ull; }
+
+// The reflected ray number k of a GGX hit (ggx_mirror.rs:66-76): direction, normalised.
+RT_HD D3 ggx_child_direction(const D3 &n, const D3 &incoming, double alpha, uint64_t sample_index, uint64_t child_path, uint64_t seed);
+
 RT_HD D3 sample_ggx(const D3 &normal, double alpha, double u1, double u2) {
     const double pi = 3.14159265358979323846;
     const double phi = 2.0 * pi * u1;
@@ -40,6 +50,15 @@ RT_HD D3 sample_ggx(const D3 &normal, double alpha, double u1, double u2) {
     D3 tangent, bitangent;
     create_coordinate_system(normal, tangent, bitangent);
     return tangent * x + bitangent * y + normal * z;
+}
+
+RT_HD D3 ggx_child_direction(const D3 &n, const D3 &incoming, double alpha, uint64_t sample_index, uint64_t child_path, uint64_t seed) {
+    uint32_t x[4];
+    rt_philox4x32_10((uint32_t)sample_index, (uint32_t)(sample_index >> 32), (uint32_t)child_path, (uint32_t)(child_path >> 32),
+                     (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    const D3 m = sample_ggx(n, alpha, rt_unit_double(x[0], x[1]), rt_unit_double(x[2], x[3]));
+    const D3 outgoing = incoming - m * (2.0 * dot(incoming, m));  // ggx_mirror.rs:69
+    return normalize(outgoing);                                   // ggx_mirror.rs:74
 }
 
 struct TreeCounts {
@@ -116,6 +135,7 @@ struct TreeFrame {  // a GGX hit waiting for its reflected rays (ggx_mirror.rs:6
     ColorF acc;
     uint32_t k, samples;
     double alpha;
+    uint64_t path;  // of the ray that found this hit
     int32_t shape, tri, depth;
 };
 
@@ -123,15 +143,15 @@ struct TreeFrame {  // a GGX hit waiting for its reflected rays (ggx_mirror.rs:6
 // step() traces ONE ray of the sample's tree (and the shadow rays of the hit it finds, if that hit is lit) and returns
 // true once the colour that render_pixel adds to the pixel's sum is known.  The order of the rays, of the random draws
 // and of every sum is the order of the reference's recursion, whoever calls step() and however other samples' steps
-// are interleaved with it; `draws` counts the pairs drawn so far, `sample_index` is the frame-wide sample index (the
-// generator's counter).
+// are interleaved with it; `path` is the current ray's path in the tree and `sample_index` the frame-wide sample index
+// (together the generator's counter).
 // (The stack of waiting GGX hits is the caller's array, not a member: an array that is indexed at run time lives in
 // scratch memory, and as a member it would take the whole walk -- current ray, depth, counters -- there with it.)
 struct TreeWalk {
     D3 o, d;
     uint64_t sample_index;
     int32_t top, depth, org_shape, org_tri;
-    uint32_t draws;
+    uint64_t path;
     float tmin, self_t;
     int32_t primary_shape, primary_tri;
 
@@ -140,7 +160,7 @@ struct TreeWalk {
         d = direction;
         sample_index = sample;
         top = -1;
-        draws = 0;
+        path = 0;
         depth = 0;
         org_shape = org_tri = -1;
         tmin = 1.0f;
@@ -197,6 +217,7 @@ struct TreeWalk {
                     f.acc = ColorF{0.0f, 0.0f, 0.0f};
                     f.k = 0; f.samples = sh.samples; f.alpha = sh.roughness;
                     f.shape = shape; f.tri = gtri; f.depth = depth;
+                    f.path = path;
                     deliver = false;  // nothing to hand over yet: go and spawn its first reflected ray
                 }
             } else {  // null.rs:7-9
@@ -222,14 +243,9 @@ struct TreeWalk {
                 top -= 1;
                 continue;
             }
-            uint32_t x[4];
-            rt_philox4x32_10((uint32_t)sample_index, (uint32_t)(sample_index >> 32), draws, 1u, (uint32_t)seed,
-                             (uint32_t)(seed >> 32), x);
-            draws += 1;
-            const D3 m = sample_ggx(f.n, f.alpha, rt_unit_double(x[0], x[1]), rt_unit_double(x[2], x[3]));
-            const D3 outgoing = f.incoming - m * (2.0 * dot(f.incoming, m));  // ggx_mirror.rs:69
+            path = tree_child_path(f.path, f.k);
             o = f.p;
-            d = normalize(outgoing);  // ggx_mirror.rs:74
+            d = ggx_child_direction(f.n, f.incoming, f.alpha, sample_index, path, seed);
             depth = f.depth + 1;
             tmin = (float)RT_VERY_SMALL_NUMBER;
             org_shape = f.shape;
