@@ -63,7 +63,7 @@
 #define RT_BLOCK 256
 #endif
 #define RT_MAX_GRID 2048  // 256 CUs x 8 resident blocks
-#define RT_TREE_ROOM 6u   // ray trees level by level: nodes a level may have for every camera ray of its batch
+#define RT_TREE_ROOM 4u   // ray trees level by level: nodes a level may have for every camera ray of its batch
 #define RT_PACKET_BLOCK 64
 // kernels that work through a chunk of RT_LIT_CHUNK samples per block
 #define RT_LIT_BLOCK RT_LIT_CHUNK
@@ -1392,9 +1392,15 @@ int ensure_buffers(RtBackend *be, uint32_t capacity, uint32_t n_point_lights) {
 // The arrays of the level-by-level ray trees for `capacity` nodes per level and levels 0 .. `levels` - 1.
 int ensure_tree_buffers(RtBackend *be, uint32_t capacity, int levels) {
     RtBackend::TreeLevels &t = be->tree;
+    if (!t.host_words) RT_HIP(hipHostMalloc((void **)&t.host_words, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!t.copied) RT_HIP(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
     if (t.capacity < capacity) {
         free_all(t.allocs);
+        uint32_t *const keep_words = t.host_words;
+        const hipEvent_t keep_event = t.copied;
         t = RtBackend::TreeLevels();
+        t.host_words = keep_words;
+        t.copied = keep_event;
         const size_t cap = capacity;
         for (int k = 0; k < 3; ++k) {
             if (int rc = alloc_into(t.allocs, &t.g_p[k], cap)) return rc;
@@ -1894,12 +1900,6 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                     hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
                 }
                 tm.end();
-                if (ds->has_lit) {
-                    if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, L, chunks);
-                    if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                    hipLaunchKernelGGL(k_shadow_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, xcd_chunk);
-                    tm.end();
-                }
                 level_nodes.push_back(nodes);
                 // how many rays the GGX hits of this level spawn
                 if ((rc = ensure_tree_buffers(be, room, level + 2))) return rc;
@@ -1913,10 +1913,25 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                 hipLaunchKernelGGL(k_tree_count, dim3(chunks), dim3(RT_LIT_THREADS), 0, stream, S, L, T, nodes);
                 hipLaunchKernelGGL(k_tree_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, T, chunks);
                 tm.end();
-                uint32_t next_nodes = 0, level_counters[RT_CNT_SIZE];
-                RT_HIP(hipMemcpyAsync(&next_nodes, T.chunk_base + chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                if (stats) RT_HIP(hipMemcpyAsync(level_counters, L.counters, sizeof(level_counters), hipMemcpyDeviceToHost, stream));
-                RT_HIP(hipStreamSynchronize(stream));
+                // The count travels to page-locked memory and the host waits for that copy alone: the level's shadow rays
+                // and light sums, which the count does not depend on, are enqueued behind the copy and keep the GPU
+                // busy while the host learns the count and enqueues the next level.
+                RT_HIP(hipMemcpyAsync(tl.host_words, T.chunk_base + chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RT_HIP(hipEventRecord(tl.copied, stream));
+                if (ds->has_lit) {
+                    if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, L, chunks);
+                    if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+                    hipLaunchKernelGGL(k_shadow_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, xcd_chunk);
+                    tm.end();
+                }
+                uint32_t level_counters[RT_CNT_SIZE];
+                if (stats) {
+                    RT_HIP(hipMemcpyAsync(level_counters, L.counters, sizeof(level_counters), hipMemcpyDeviceToHost, stream));
+                    RT_HIP(hipStreamSynchronize(stream));
+                } else {
+                    RT_HIP(hipEventSynchronize(tl.copied));
+                }
+                const uint32_t next_nodes = tl.host_words[0];
                 if (stats) {
                     for (int b = 1; b < 32; ++b) batch_secondary += level_counters[RT_CNT_RAYS0 + b];
                     batch_lit += level_counters[RT_CNT_LIT];
@@ -2181,6 +2196,9 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
         (void)hipEventDestroy(p.b);
     }
     free_all(be->buf_allocs);
+    free_all(be->tree.allocs);
+    if (be->tree.host_words) (void)hipHostFree(be->tree.host_words);
+    if (be->tree.copied) (void)hipEventDestroy(be->tree.copied);
     if (be->tile_list) (void)hipFree(be->tile_list);
     if (be->tile_where) (void)hipFree(be->tile_where);
     if (be->fb) (void)hipFree(be->fb);

@@ -61,6 +61,10 @@ struct RtBackend {
         // per level (level 0 is the batch's samples, whose colours are the batch's own colour array)
         std::vector<float *> color;      // [3 * capacity]
         std::vector<uint32_t *> base, count;  // [capacity] children of each node: where they start in the next level, how many
+        // how many rays the next level has, read by the host between levels: page-locked, so that the copy is only
+        // enqueued, and an event behind it, so that the host need not wait for what is enqueued behind the copy
+        uint32_t *host_words = nullptr;
+        hipEvent_t copied = nullptr;
     } tree;
     // tile list of the last partition
     int32_t *tile_list = nullptr;

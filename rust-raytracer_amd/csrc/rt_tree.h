@@ -41,12 +41,17 @@ RT_HD uint64_t tree_child_path(uint64_t path, uint32_t k) { return (path << 8) +
 // The reflected ray number k of a GGX hit (ggx_mirror.rs:66-76): direction, normalised.
 RT_HD D3 ggx_child_direction(const D3 &n, const D3 &incoming, double alpha, uint64_t sample_index, uint64_t child_path, uint64_t seed);
 
+// (theta = atan(r) with r = sqrt(alpha^2 u2 / (1 - u2)) >= 0 is only ever used through its sine and cosine, which are
+// r / sqrt(1 + r^2) and 1 / sqrt(1 + r^2): the same numbers to a unit in the last place without the arc tangent and
+// two of the four trigonometric calls, which were most of what spawning a ray cost.)
 RT_HD D3 sample_ggx(const D3 &normal, double alpha, double u1, double u2) {
     const double pi = 3.14159265358979323846;
     const double phi = 2.0 * pi * u1;
-    const double theta = atan(sqrt(alpha * alpha * u2 / (1.0 - u2)));
-    const double sin_theta = sin(theta), cos_theta = cos(theta);
-    const double x = sin_theta * cos(phi), y = sin_theta * sin(phi), z = cos_theta;
+    const double r = sqrt(alpha * alpha * u2 / (1.0 - u2));
+    const double cos_theta = 1.0 / sqrt(1.0 + r * r), sin_theta = r * cos_theta;
+    double sin_phi, cos_phi;
+    sincos(phi, &sin_phi, &cos_phi);
+    const double x = sin_theta * cos_phi, y = sin_theta * sin_phi, z = cos_theta;
     D3 tangent, bitangent;
     create_coordinate_system(normal, tangent, bitangent);
     return tangent * x + bitangent * y + normal * z;

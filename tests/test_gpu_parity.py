@@ -795,6 +795,59 @@ def test_ggx_ray_trees_match_oracle(rt, backend, mode):
     dev.close()
 
 
+def test_ggx_level_by_level_and_depth_first_agree(rt, backend):
+    """The two ways through a ray tree: level by level through the packet kernels (what rt_render does in fast mode)
+    and one lane per tree, depth first (RT_RENDER_TREE_DEPTH_FIRST; what enqueue-only calls, reference-order mode
+    and the static work memory use).  Same rays, same random numbers (keyed by the ray's path in its tree), same
+    order of every sum; the light sums are f32 in the first and f64 in the second, so colours agree to a few
+    units in the last place of an f32, not bit for bit.  Also: batches so small that a level outgrows the work
+    buffers (the batch is halved, a single tile falls back to the depth-first kernel) change nothing visible."""
+    scene = rt.parse_scene(edge_scenes.ggx_scene(samples=6), "", image_width=160, image_height=120, recursion_depth=3)
+    dev = backend.upload(scene)
+    levels, ids_l, st_l = dev.render(2, seed=7, want_ids=True)
+    depth, ids_d, st_d = dev.render(2, seed=7, want_ids=True, flags=rt.RT_RENDER_TREE_DEPTH_FIRST)
+    assert np.array_equal(ids_l.primary_shape, ids_d.primary_shape)
+    assert [st_l.primary_rays, st_l.secondary_rays, st_l.shadow_rays] == [st_d.primary_rays, st_d.secondary_rays, st_d.shadow_rays]
+    assert st_l.secondary_rays > 6 * 160 * 120
+    diff = np.abs(levels.pixels - depth.pixels)
+    assert diff.max() <= 2e-5, diff.max()
+    # without statistics (a wave per packet in the bounce kernel, the count read behind an event): the same frame
+    quiet, _, _ = dev.render(2, seed=7, want_stats=False)
+    assert np.array_equal(quiet.pixels, levels.pixels)
+    # A level holds at most the batch buffers' samples.  With room for 8 tiles of 8 x 8 pixels a batch of camera rays is
+    # two tiles, and with six reflected rays per rough hit a level outgrows the room where the rough mirrors fill the
+    # tiles: such a batch is halved (seen as more batches than 300 / 2 by the progress callback).  With room for 4 tiles
+    # a batch is one tile, and a tile that does not fit goes through the depth-first kernel: it equals that frame bit
+    # for bit, the other tiles the level-by-level frame.
+    # (On backends of their own: a backend's buffers only ever grow, and the frames above have made this one's large.)
+    calls = []
+    be8, be4 = rt.Backend(0), rt.Backend(0)
+    dev8, dev4 = be8.upload(scene), be4.upload(scene)
+    small, _, st_s = dev8.render(2, seed=7, tile=(8, 8), batch_samples=8 * 8 * 8 * 4, progress=lambda done, total: calls.append(done))
+    assert np.array_equal(small.pixels, levels.pixels) or np.abs(small.pixels - levels.pixels).max() <= 2e-5
+    print("batches with room for 8 tiles:", len(calls))
+    assert len(calls) > 150
+    tiny, _, st_t = dev4.render(2, seed=7, tile=(8, 8), batch_samples=4 * 8 * 8 * 4)
+    by_levels = by_depth = 0
+    for ty in range(0, 120, 8):
+        for tx in range(0, 160, 8):
+            t = tiny.pixels[ty:ty + 8, tx:tx + 8]
+            same_l = np.array_equal(t, levels.pixels[ty:ty + 8, tx:tx + 8])
+            same_d = np.array_equal(t, depth.pixels[ty:ty + 8, tx:tx + 8])
+            assert same_l or same_d, (tx, ty)
+            by_levels += same_l and not same_d
+            by_depth += same_d and not same_l
+    print("tiles only equal to the level-by-level frame:", by_levels, "only to the depth-first frame:", by_depth)
+    assert by_levels > 0 and by_depth > 0
+    assert [st_t.primary_rays, st_t.secondary_rays, st_t.shadow_rays] == [st_l.primary_rays, st_l.secondary_rays, st_l.shadow_rays]
+    for d in (dev8, dev4):
+        d.close()
+    for b in (be8, be4):
+        b.close()
+    assert [st_s.primary_rays, st_s.secondary_rays, st_s.shadow_rays] == [st_l.primary_rays, st_l.secondary_rays, st_l.shadow_rays]
+    dev.close()
+
+
 def test_ggx_matches_committed_fixture(rt, backend):
     g = np.load(os.path.join(GOLDEN, "render_ggx_scene.npz"))
     scene = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=64, image_height=48, recursion_depth=3)

@@ -17,6 +17,11 @@ def main():
     sc = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=1000, image_height=1000, recursion_depth=3)
     be = rt.Backend(0)
     dev = be.upload(sc)
+    if len(sys.argv) > 1 and sys.argv[1] == "trace":  # under rocprofv3 --kernel-trace: ten frames without statistics, nothing else
+        pinned = rt.HostBuffer((1000, 1000, 3))
+        for _ in range(10):
+            dev.render(2, seed=1, want_stats=False, out=pinned.array)
+        return
     dev.render(2, seed=1)
     best = None
     for _ in range(3):
@@ -26,6 +31,20 @@ def main():
         best = st if best is None or st.render_ms < best.render_ms else best
     print(f"ggx_scene 1000x1000 rpp4 depth3: device {best.render_ms:.2f} ms, rays {best.total_rays()}, "
           f"{best.total_rays() / best.render_ms / 1e6:.2f} Grays/s")
+    print("   kernel classes, ms (each kernel alone on the GPU):", {rt.KERNEL_CLASSES[k]: round(best.kernel_ms[k], 3) for k in range(len(rt.KERNEL_CLASSES))},
+          "primary / secondary / shadow rays:", best.primary_rays, best.secondary_rays, best.shadow_rays)
+    # the same frame without statistics (no event pairs, a wave per packet in the bounce kernel), into page-locked memory:
+    # what a caller of rt_render sees, and the depth-first kernel beside it
+    pinned = rt.HostBuffer((1000, 1000, 3))
+    for flags, name in ((0, "level by level"), (rt.RT_RENDER_TREE_DEPTH_FIRST, "depth first")):
+        for _ in range(3):
+            dev.render(2, seed=1, want_stats=False, out=pinned.array, flags=flags)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dev.render(2, seed=1, want_stats=False, out=pinned.array, flags=flags)
+        dt = (time.perf_counter() - t0) / 10
+        print(f"   rt_render, no statistics, {name}: {dt * 1e3:.2f} ms per frame, {best.total_rays() / dt / 1e9:.2f} Grays/s")
+    pinned.close()
     dev.close()
     be.close()
 
