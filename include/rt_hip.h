@@ -120,8 +120,13 @@ int rt_scene_upload_with(RtBackend *backend, const RtScene *scene, const RtUploa
  * rand's f64).  A frame therefore depends only on (scene, n, method, seed): not on the
  * tiling, the partition over GPUs or the traversal mode.
  * GGXMirror (ggx_mirror.rs:33-34, two uniform numbers per reflected ray) draws from the same
- * generator: the k-th pair of a sample, k counted in the order of the reference's recursion, has
- * counter (sample index low word, high word, k, 1). */
+ * generator, keyed by the ray's PATH in its sample's ray tree: the camera ray has path 0, the
+ * k-th ray (k = 0, 1, ...) spawned at the GGX hit of a ray of path P has path (P << 8) + k + 1
+ * (64 bits, wrapping), a perfect mirror passes its ray's path on; the pair that shapes a ray has
+ * counter (sample index low word, high word, path low word, path high word).  A path is never 0,
+ * so these counters never meet the sample offsets'.  A ray's numbers thus do not depend on what
+ * the other rays of its tree hit: the tree may be traced in any order (rand::thread_rng() makes
+ * the order of the reference's recursion unobservable). */
 enum { RT_AA_NORMAL = 0, RT_AA_JITTERED = 1, RT_AA_RANDOM = 2 };
 
 /* Traversal policy.  Both produce the same closest hits except at exact ties.
@@ -213,8 +218,12 @@ enum {
                                        hits as two launches (the hit records go through memory) instead of one, and
                                        likewise two launches per mirror bounce instead of one for all bounces */
     RT_RENDER_TREE_DEPTH_FIRST = 16 /* scenes with a GGXMirror shader: one thread walks a sample's whole ray tree, depth
-                                       first, even where the tree could be traced level by level (RT_MODE_FAST in a
-                                       call that waits for its frame: rt_render, or any call that asks for statistics) */
+                                       first.  Without it RT_MODE_FAST traces the trees level by level through the
+                                       packet kernels, four times as fast, but every call -- the enqueue-only ones
+                                       too -- then waits for the device once per level (it reads how many rays the
+                                       next level has); with it rt_render_async and rt_render_device only enqueue,
+                                       as they do for every other scene.  Same rays and random numbers either way;
+                                       colours agree to a few units in the last place of an f32 */
 };
 
 /* Optional per-sample outputs.  Sample s of pixel (i, j) is

@@ -1697,11 +1697,14 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     }
     uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
     uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
-    // Ray trees level by level (see k_tree_count): fast mode with all its fused kernels, in a call that may wait for
-    // the device between levels (it reads how many rays the next level has).  A level's rays lie in the batch
-    // buffers like a batch's samples, so a batch of camera rays is sized to leave room for levels that are larger
-    // than it: RT_TREE_ROOM times.  A level that still does not fit halves the batch (below).
-    const bool tree_levels = ds->has_ggx && args->mode == RT_MODE_FAST && !static_memory && (blocking || stats != nullptr) &&
+    // Ray trees level by level (see k_tree_count): fast mode with all its fused kernels.  The call waits for the device
+    // between levels (it reads how many rays the next level has), enqueue-only entry points too: a frame takes a
+    // quarter of the depth-first kernel's time, which is worth more to a stream of frames than a call that returns
+    // at once (RT_RENDER_TREE_DEPTH_FIRST is for callers who must not wait; the static work memory, whose users
+    // may be capturing a graph, always goes depth first).  A level's rays lie in the batch buffers like a batch's
+    // samples, so a batch of camera rays is sized to leave room for levels that are larger than it: RT_TREE_ROOM
+    // times.  A level that still does not fit halves the batch (below).
+    const bool tree_levels = ds->has_ggx && args->mode == RT_MODE_FAST && !static_memory &&
                              (args->flags & (RT_RENDER_TREE_DEPTH_FIRST | RT_RENDER_NO_PACKETS | RT_RENDER_UNFUSED_SHADOWS | RT_RENDER_UNFUSED_CAMERA)) == 0u &&
                              ds->n_point_lights <= 32;
     if (tree_levels) {
