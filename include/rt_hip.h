@@ -174,7 +174,7 @@ typedef struct RtRenderArgs {
     void *progress_user;
     /* Tuning; 0 = the library's choice everywhere.  None of them changes a pixel.
      *  batch_samples  most samples (pixels x rays per pixel) worked on at a time; a larger frame is
-     *                 rendered in several batches of whole tiles (0 -> 16 Mi, about 1.9 GB of queues)
+     *                 rendered in several batches of whole tiles (0 -> 32 Mi, about 8.5 GB of work buffers)
      *  xcd_chunk      consecutive 256-sample blocks handed to one XCD (one L2) at a time (rounded down to a power of two)
      *  flags          RT_RENDER_* below */
     uint32_t batch_samples;

@@ -741,6 +741,22 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
 // `tally_on` = 0, and the grid is a wave per packet, which the hardware deals out as waves finish -- mirror
 // chains differ in length (22 616 packets at bounce 1, 2909 at bounce 2, 42 at bounce 6 in cornell_room) and a fixed
 // deal waits for its unluckiest wave (one blocking frame 0.900 -> 0.858 ms).
+#define RT_BOUNCE_KEEP 17
+__device__ __forceinline__ void keep_ray(int32_t *keep, const D3 &o, const D3 &d) {
+    const double v[6] = {o.x, o.y, o.z, d.x, d.y, d.z};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        keep[(2 * k) * RT_PACKET_BLOCK] = __double2loint(v[k]);
+        keep[(2 * k + 1) * RT_PACKET_BLOCK] = __double2hiint(v[k]);
+    }
+}
+__device__ __forceinline__ void kept_ray(const int32_t *keep, D3 &o, D3 &d) {
+    double v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = __hiloint2double(keep[(2 * k + 1) * RT_PACKET_BLOCK], keep[(2 * k) * RT_PACKET_BLOCK]);
+    o = D3{v[0], v[1], v[2]};
+    d = D3{v[3], v[4], v[5]};
+}
 struct BouncePacketKernargs {
     RtSceneView S;
     RtBuffers Q;
@@ -778,6 +794,14 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
     uint32_t *tally = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows));
     tally[threadIdx.x] = 0u;
     __syncthreads();
+    // What a lane knows about its ray waits in LDS, a column of RT_BOUNCE_KEEP words behind the tally: the f64 ray
+    // (needed for the fp32 search before the walk and for the hit point after it), the sample it belongs to, the
+    // depth it started at, and for a ray that a mirror of this kernel made, the primitive it starts on.  The queue
+    // is read once, by a ray's first round; a reflected ray goes from round to round through these words and never
+    // to memory.  (Reading the ray again after the walk, and a reflected ray back from its queue slot, was a memory
+    // round trip of 1.5 - 2 us each in a round of 11, and 120 bytes per ray from HBM where the rays of a ray tree's
+    // level make this kernel's time.)
+    int32_t *keep = lds + rt_packet_lds_dwords(rows) + RT_PACKET_BLOCK + threadIdx.x;
     constexpr int which = 1;  // the queue of bounce 1
     // the queue has a stretch per chunk of samples (RtBuffers::mirror_counts): the waves stride over all packets
     // of all stretches and pass over those behind a stretch's last ray
@@ -803,10 +827,22 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
                 float t0 = -__builtin_inff();  // a slot without a ray: an empty search interval
                 int32_t shape0 = -1, org_shape = -1, org_tri = -1;
                 if (going) {
-                    queue_read_ray(K.Q, which, idx, o, d);
-                    org_shape = K.Q.q_org_shape[which][idx];
-                    org_tri = K.Q.q_org_tri[which][idx];
-                    t0 = K.Q.q_self_t[which][idx];  // the origin primitive's own re-hit, or +inf
+                    if (b == 1) {
+                        queue_read_ray(K.Q, which, idx, o, d);
+                        org_shape = K.Q.q_org_shape[which][idx];
+                        org_tri = K.Q.q_org_tri[which][idx];
+                        t0 = K.Q.q_self_t[which][idx];  // the origin primitive's own re-hit, or +inf
+                        keep[12 * RT_PACKET_BLOCK] = K.Q.q_sample[which][idx];
+                        // reflections in front of this ray: one, or (a level of ray trees, whose rays start at different
+                        // depths) what the ray was spawned with
+                        keep[13 * RT_PACKET_BLOCK] = K.Q.n_depth != nullptr ? K.Q.n_depth[idx] : 1;
+                        keep_ray(keep, o, d);
+                    } else {
+                        kept_ray(keep, o, d);
+                        org_shape = keep[14 * RT_PACKET_BLOCK];
+                        org_tri = keep[15 * RT_PACKET_BLOCK];
+                        t0 = __int_as_float(keep[16 * RT_PACKET_BLOCK]);
+                    }
                     if (t0 < __builtin_inff()) shape0 = org_shape;
                 }
                 fast_set_ray(st[0], (float)o.x, (float)o.y, (float)o.z, (float)d.x, (float)d.y, (float)d.z);
@@ -822,21 +858,23 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
             if (b <= 6) wave_log(2u * n_packets + (blk * 6u + (uint32_t)(b - 1)) * 2u, bounce_t0);
 #endif
             const BouncePacketKernargs &L = fresh(args);
-            const uint32_t idx = opaque(idx0);
             MirrorTmp tmp;
             int act = RT_ACT_NONE;
             int32_t sample = 0;
             if (going) {
                 D3 o, d;
-                sample = L.Q.q_sample[which][idx];
-                queue_read_ray(L.Q, which, idx, o, d);
-                // reflections in front of this ray: the round's number, or (a level of ray trees, whose rays start at
-                // different depths) what the ray started with plus the mirrors since
-                const int depth = L.Q.n_depth != nullptr ? L.Q.n_depth[idx] + b - 1 : b;
+                kept_ray(keep, o, d);
+                sample = keep[12 * RT_PACKET_BLOCK];
+                const int depth = keep[13 * RT_PACKET_BLOCK] + b - 1;  // what the ray started with plus the mirrors since
                 act = shade_hit(L.S, L.Q, L.B, L.ids, depth, sample, o, d, st[0].shape, st[0].tri, st[0].t, tmp);
             }
             going = act == RT_ACT_MIRROR;
-            if (going) queue_write_ray(L.Q, which, idx, tmp);
+            if (going) {  // the reflected ray, for the next round
+                keep_ray(keep, tmp.p, tmp.d);
+                keep[14 * RT_PACKET_BLOCK] = tmp.shape;
+                keep[15 * RT_PACKET_BLOCK] = tmp.tri;
+                keep[16 * RT_PACKET_BLOCK] = __float_as_int(tmp.self_t);
+            }
             const unsigned long long on = __ballot(going);
             if (tally_on != 0u && on != 0ull && threadIdx.x == 0u) tally[b & 31] += (uint32_t)__popcll(on);  // rays of bounce b + 1
             unsigned long long todo = __ballot(act == RT_ACT_LIT);
@@ -1668,7 +1706,9 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     const uint32_t n_slots = static_memory ? tiles_x * tiles_y : (uint32_t)be->tile_list_host.size();
 
     // ---- batch size
-    const uint64_t max_batch = args->batch_samples ? args->batch_samples : (16ull << 20);
+    // (32 Mi samples, 8.5 GB of work buffers with two point lights: the 3840 x 2160 frame at 64 rays per pixel takes
+    // 36.3 ms in batches of 16 Mi, 35.4 of 32 Mi, 34.9 of 64 Mi -- fewer, larger launches, fewer kernel tails)
+    const uint64_t max_batch = args->batch_samples ? args->batch_samples : (32ull << 20);
     uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / tile_samples);
     RtBuffers carved;
     if (static_memory) {
@@ -1780,6 +1820,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // stack rows, the world-space rays of a wave inside an instance, and (fused kernel) a word per lane
     const size_t packet_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 7u * 64u) * sizeof(int32_t);  // + the fused kernel's seven words per lane
     const size_t camera_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 4u * 64u) * sizeof(int32_t);  // + the plane point
+    const size_t bounce_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + (1u + RT_BOUNCE_KEEP) * 64u) * sizeof(int32_t);  // + tally, kept ray
     // a wait per batch: to read the counters for the statistics, or to serve the progress callback
     const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
     const bool wait_batches = stats != nullptr || serve_progress;
@@ -1900,7 +1941,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                     hipLaunchKernelGGL(k_camera_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, L, B, level_io, nodes, xcd_chunk, 0u);
                 if (level > 0 || ds->has_mirror) {
                     const uint32_t gp = stats ? std::min<uint32_t>(grid_packets, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : grid_packets;
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
                 }
                 tm.end();
                 level_nodes.push_back(nodes);
@@ -2000,7 +2041,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                     // counts to the batch's counters once each.  Without: a wave per packet, dealt by the hardware
                     // as waves finish (mirror chains differ in length; a fixed deal waits for its unluckiest wave).
                     const uint32_t gp = stats ? std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : packet_grid;
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u);
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u);
                 } else {
                     const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
                     hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);

@@ -643,7 +643,7 @@ def test_window_render_equals_the_same_pixels_of_the_whole_frame(rt, backend, sc
 
 
 def test_4k_rpp64_config_whole_and_in_eight_parts(rt, backend, scene_path):
-    """bunny 3840x2160, 64 rays per pixel, depth 6 (530.8 M camera rays, 32 batches of 16 Mi samples):
+    """bunny 3840x2160, 64 rays per pixel, depth 6 (530.8 M camera rays, 16 batches of 32 Mi samples):
     the frame rendered whole equals the frame rendered as 8 interleaved parts and un-tiled, bit for
     bit and ray for ray; and on four windows of 128 x 96 pixels (silhouettes, ground with shadows,
     background) the ids of every sample and the 8-bit image match the oracle, in both modes."""
@@ -679,7 +679,7 @@ def test_4k_rpp64_config_whole_and_in_eight_parts(rt, backend, scene_path):
         a = dev.render_args(n, mode=mode, tile=(tile, tile))
         st = dev.render_device(a, fb.data_ptr(), ids=ids, want_stats=True)
         assert st.primary_rays == W * H * spp
-        assert st.kernel_launches[rt.KERNEL_CLASSES.index("resolve")] >= 30  # 16 Mi samples per batch
+        assert st.kernel_launches[rt.KERNEL_CLASSES.index("resolve")] >= 15  # 32 Mi samples per batch
         image = fb.cpu().numpy().reshape(H, W, 3)
         whole_pixels[mode] = (image, st.total_rays())
         for w, (ref_fb, ref_ids, _) in zip(windows, ref):
