@@ -1610,6 +1610,136 @@ bool rt::is_pinned_host(const void *p) {
     return attr.type == hipMemoryTypeHost;
 }
 
+namespace {
+
+// One batch of ray trees, level by level (see k_tree_count): level 0 = the batch's camera rays, level L + 1 = what the
+// GGX hits of level L spawn, each level through the fast mode's fused kernels with `Q`'s arrays as its work memory;
+// then the children's colours into their parents, deepest level first, which leaves the samples' colours in Q.color.
+// `too_large`: a level has more rays than Q holds and nothing of the batch is to be used (the caller renders the
+// same tiles in smaller batches).  `secondary`, `lit`: what the levels' counters came to (with `stats`).
+struct TreeBatch {
+    bool too_large = false;
+    uint64_t secondary = 0, lit = 0;
+};
+int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, hipStream_t stream, bool stats, Timing &tm,
+                      const RtSceneView &S, RtBuffers Q, const RtBatch &B, const RtIdOut &io, uint32_t n_samples, size_t camera_lds,
+                      size_t packet_lds, size_t bounce_lds, TreeBatch &out) {
+    int rc = RT_OK;
+    // ---- level 0: the camera rays; level L + 1: what the GGX hits of level L spawn (see k_tree_count)
+    RtBackend::TreeLevels &tl = be->tree;
+    const uint32_t room = Q.capacity;
+    uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
+                               Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
+    for (int k = 0; k < 3; ++k) {
+        Q.g_p[k] = tl.g_p[k];
+        Q.g_n[k] = tl.g_n[k];
+        Q.g_in[k] = tl.g_in[k];
+    }
+    Q.g_shape = tl.g_shape; Q.g_tri = tl.g_tri; Q.g_mark = tl.g_mark;
+    std::vector<uint32_t> level_nodes;  // rays per level
+    bool too_large = false;
+    uint64_t batch_secondary = 0, batch_lit = 0;
+    uint32_t nodes = n_samples;
+    for (int level = 0;; ++level) {
+        // this level's rays through the stages
+        RtBuffers L = Q;
+        const uint32_t chunks = (nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
+        L.counters = sets[level & 1];
+        L.block_counts = L.counters + RT_CNT_SIZE;
+        L.mirror_counts = L.block_counts + chunks;
+        L.counters_next = sets[(level & 1) ^ 1];
+        L.color = level == 0 ? Q.color : tl.color[(size_t)level];
+        L.n_depth = level == 0 ? nullptr : tl.depth[level & 1];
+        const uint32_t grid_packets = (nodes + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+        const uint32_t grid_threads = (nodes + RT_BLOCK - 1) / RT_BLOCK;
+        uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, grid_threads / 256u));
+        while ((xcd_chunk & (xcd_chunk - 1u)) != 0u) xcd_chunk &= xcd_chunk - 1u;
+        const RtIdOut level_io = level == 0 ? io : RtIdOut{};
+        if (level == 0) {
+            RT_HIP(hipMemsetAsync(L.counters, 0, ((size_t)RT_CNT_SIZE + 2u * chunks) * sizeof(uint32_t), stream));
+        } else {
+            // (this level's counters were cleared before its rays were made: the spawn kernel has written the
+            // queue's stretch lengths into them)
+        }
+        RT_HIP(hipMemsetAsync(Q.g_mark, 0xff, (size_t)nodes * sizeof(int32_t), stream));
+        if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        if (level == 0)
+            hipLaunchKernelGGL(k_camera_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, L, B, level_io, nodes, xcd_chunk, 0u);
+        if (level > 0 || ds->has_mirror) {
+            const uint32_t gp = stats ? std::min<uint32_t>(grid_packets, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : grid_packets;
+            hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
+        }
+        tm.end();
+        level_nodes.push_back(nodes);
+        // how many rays the GGX hits of this level spawn
+        if ((rc = ensure_tree_buffers(be, room, level + 2))) return rc;
+        TreeLevelView T{};
+        T.off = tl.off; T.chunk_base = tl.chunk_base; T.parent = tl.parent;
+        T.base = tl.base[(size_t)level]; T.count = tl.count[(size_t)level];
+        T.root_in = tl.root[level & 1]; T.path_in = tl.path[level & 1];
+        T.root_out = tl.root[(level & 1) ^ 1]; T.path_out = tl.path[(level & 1) ^ 1];
+        T.depth_out = tl.depth[(level & 1) ^ 1];
+        if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        hipLaunchKernelGGL(k_tree_count, dim3(chunks), dim3(RT_LIT_THREADS), 0, stream, S, L, T, nodes);
+        hipLaunchKernelGGL(k_tree_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, T, chunks);
+        tm.end();
+        // The count travels to page-locked memory and the host waits for that copy alone: the level's shadow rays
+        // and light sums, which the count does not depend on, are enqueued behind the copy and keep the GPU
+        // busy while the host learns the count and enqueues the next level.
+        RT_HIP(hipMemcpyAsync(tl.host_words, T.chunk_base + chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipEventRecord(tl.copied, stream));
+        if (ds->has_lit) {
+            if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, L, chunks);
+            if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            hipLaunchKernelGGL(k_shadow_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, xcd_chunk);
+            tm.end();
+        }
+        uint32_t level_counters[RT_CNT_SIZE];
+        if (stats) {
+            RT_HIP(hipMemcpyAsync(level_counters, L.counters, sizeof(level_counters), hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipStreamSynchronize(stream));
+        } else {
+            RT_HIP(hipEventSynchronize(tl.copied));
+        }
+        const uint32_t next_nodes = tl.host_words[0];
+        if (stats) {
+            for (int b = 1; b < 32; ++b) batch_secondary += level_counters[RT_CNT_RAYS0 + b];
+            batch_lit += level_counters[RT_CNT_LIT];
+        }
+        if (next_nodes == 0u) break;
+        if (next_nodes > room) {
+            too_large = true;
+            break;
+        }
+        // the next level's rays
+        RtBuffers N = Q;
+        const uint32_t next_chunks = (next_nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
+        N.counters = sets[(level & 1) ^ 1];
+        N.block_counts = N.counters + RT_CNT_SIZE;
+        N.mirror_counts = N.block_counts + next_chunks;
+        RT_HIP(hipMemsetAsync(N.counters, 0, ((size_t)RT_CNT_SIZE + 2u * next_chunks) * sizeof(uint32_t), stream));
+        if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        hipLaunchKernelGGL(k_tree_link, dim3(grid_threads), dim3(RT_BLOCK), 0, stream, S, L, T, nodes);
+        hipLaunchKernelGGL(k_tree_spawn, dim3((next_nodes + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, S, N, B, T, (uint32_t)level, next_nodes);
+        tm.end();
+        nodes = next_nodes;
+    }
+    out.secondary = batch_secondary;
+    out.lit = batch_lit;
+    out.too_large = too_large;
+    if (too_large) return RT_OK;
+    // the children's colours into their parents, deepest level first
+    if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+    for (int level = (int)level_nodes.size() - 2; level >= 0; --level)
+        hipLaunchKernelGGL(k_tree_gather, dim3((level_nodes[(size_t)level] + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream,
+                           tl.base[(size_t)level], tl.count[(size_t)level], tl.color[(size_t)level + 1],
+                           level == 0 ? Q.color : tl.color[(size_t)level], level_nodes[(size_t)level]);
+    tm.end();
+    return RT_OK;
+}
+
+}  // namespace
+
 int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
                      hipStream_t stream, RtStats *stats, bool blocking, bool static_memory) {
     if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
@@ -1899,124 +2029,20 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
         const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
         if (tree_levels && !tree_depth_first) {
-            // ---- level 0: the camera rays; level L + 1: what the GGX hits of level L spawn (see k_tree_count)
-            RtBackend::TreeLevels &tl = be->tree;
-            const uint32_t room = Q.capacity;
-            uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
-                                       Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
-            for (int k = 0; k < 3; ++k) {
-                Q.g_p[k] = tl.g_p[k];
-                Q.g_n[k] = tl.g_n[k];
-                Q.g_in[k] = tl.g_in[k];
-            }
-            Q.g_shape = tl.g_shape; Q.g_tri = tl.g_tri; Q.g_mark = tl.g_mark;
-            std::vector<uint32_t> level_nodes;  // rays per level
-            bool too_large = false;
-            uint64_t batch_secondary = 0, batch_lit = 0;
-            uint32_t nodes = n_samples;
-            for (int level = 0;; ++level) {
-                // this level's rays through the stages
-                RtBuffers L = Q;
-                const uint32_t chunks = (nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
-                L.counters = sets[level & 1];
-                L.block_counts = L.counters + RT_CNT_SIZE;
-                L.mirror_counts = L.block_counts + chunks;
-                L.counters_next = sets[(level & 1) ^ 1];
-                L.color = level == 0 ? Q.color : tl.color[(size_t)level];
-                L.n_depth = level == 0 ? nullptr : tl.depth[level & 1];
-                const uint32_t grid_packets = (nodes + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
-                const uint32_t grid_threads = (nodes + RT_BLOCK - 1) / RT_BLOCK;
-                uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, grid_threads / 256u));
-                while ((xcd_chunk & (xcd_chunk - 1u)) != 0u) xcd_chunk &= xcd_chunk - 1u;
-                const RtIdOut level_io = level == 0 ? io : RtIdOut{};
-                if (level == 0) {
-                    RT_HIP(hipMemsetAsync(L.counters, 0, ((size_t)RT_CNT_SIZE + 2u * chunks) * sizeof(uint32_t), stream));
-                } else {
-                    // (this level's counters were cleared before its rays were made: the spawn kernel has written the
-                    // queue's stretch lengths into them)
-                }
-                RT_HIP(hipMemsetAsync(Q.g_mark, 0xff, (size_t)nodes * sizeof(int32_t), stream));
-                if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                if (level == 0)
-                    hipLaunchKernelGGL(k_camera_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, L, B, level_io, nodes, xcd_chunk, 0u);
-                if (level > 0 || ds->has_mirror) {
-                    const uint32_t gp = stats ? std::min<uint32_t>(grid_packets, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : grid_packets;
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
-                }
-                tm.end();
-                level_nodes.push_back(nodes);
-                // how many rays the GGX hits of this level spawn
-                if ((rc = ensure_tree_buffers(be, room, level + 2))) return rc;
-                TreeLevelView T{};
-                T.off = tl.off; T.chunk_base = tl.chunk_base; T.parent = tl.parent;
-                T.base = tl.base[(size_t)level]; T.count = tl.count[(size_t)level];
-                T.root_in = tl.root[level & 1]; T.path_in = tl.path[level & 1];
-                T.root_out = tl.root[(level & 1) ^ 1]; T.path_out = tl.path[(level & 1) ^ 1];
-                T.depth_out = tl.depth[(level & 1) ^ 1];
-                if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                hipLaunchKernelGGL(k_tree_count, dim3(chunks), dim3(RT_LIT_THREADS), 0, stream, S, L, T, nodes);
-                hipLaunchKernelGGL(k_tree_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, T, chunks);
-                tm.end();
-                // The count travels to page-locked memory and the host waits for that copy alone: the level's shadow rays
-                // and light sums, which the count does not depend on, are enqueued behind the copy and keep the GPU
-                // busy while the host learns the count and enqueues the next level.
-                RT_HIP(hipMemcpyAsync(tl.host_words, T.chunk_base + chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                RT_HIP(hipEventRecord(tl.copied, stream));
-                if (ds->has_lit) {
-                    if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, L, chunks);
-                    if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                    hipLaunchKernelGGL(k_shadow_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, L, B, level_io, xcd_chunk);
-                    tm.end();
-                }
-                uint32_t level_counters[RT_CNT_SIZE];
-                if (stats) {
-                    RT_HIP(hipMemcpyAsync(level_counters, L.counters, sizeof(level_counters), hipMemcpyDeviceToHost, stream));
-                    RT_HIP(hipStreamSynchronize(stream));
-                } else {
-                    RT_HIP(hipEventSynchronize(tl.copied));
-                }
-                const uint32_t next_nodes = tl.host_words[0];
-                if (stats) {
-                    for (int b = 1; b < 32; ++b) batch_secondary += level_counters[RT_CNT_RAYS0 + b];
-                    batch_lit += level_counters[RT_CNT_LIT];
-                }
-                if (next_nodes == 0u) break;
-                if (next_nodes > room) {
-                    too_large = true;
-                    break;
-                }
-                // the next level's rays
-                RtBuffers N = Q;
-                const uint32_t next_chunks = (next_nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
-                N.counters = sets[(level & 1) ^ 1];
-                N.block_counts = N.counters + RT_CNT_SIZE;
-                N.mirror_counts = N.block_counts + next_chunks;
-                RT_HIP(hipMemsetAsync(N.counters, 0, ((size_t)RT_CNT_SIZE + 2u * next_chunks) * sizeof(uint32_t), stream));
-                if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                hipLaunchKernelGGL(k_tree_link, dim3(grid_threads), dim3(RT_BLOCK), 0, stream, S, L, T, nodes);
-                hipLaunchKernelGGL(k_tree_spawn, dim3((next_nodes + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, S, N, B, T, (uint32_t)level, next_nodes);
-                tm.end();
-                nodes = next_nodes;
-            }
-            if (too_large) {
+            TreeBatch levels;
+            if ((rc = tree_levels_batch(be, ds, args, stream, stats != nullptr, tm, S, Q, B, io, n_samples, camera_lds, packet_lds, bounce_lds, levels)))
+                return rc;
+            be->counter_dirty[0] = be->counter_dirty[1] = ~0u;  // the levels took turns with both sets
+            if (levels.too_large) {
                 // A level has more rays than the buffers hold: the same tiles again in smaller batches (a ray's numbers
                 // do not depend on its batch), and a single tile that does not fit through the depth-first kernel.
-                be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
                 if (slots > 1) tree_slots = std::max(1u, slots / 2u);
                 else tree_depth_first = true;
                 step = 0;
                 continue;
             }
-            // the children's colours into their parents, deepest level first
-            if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            for (int level = (int)level_nodes.size() - 2; level >= 0; --level)
-                hipLaunchKernelGGL(k_tree_gather, dim3((level_nodes[(size_t)level] + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream,
-                                   tl.base[(size_t)level], tl.count[(size_t)level], tl.color[(size_t)level + 1],
-                                   level == 0 ? Q.color : tl.color[(size_t)level], level_nodes[(size_t)level]);
-            tm.end();
-            tree_secondary += batch_secondary;
-            tree_lit += batch_lit;
-            be->counter_dirty[0] = be->counter_dirty[1] = ~0u;  // the levels took turns with both sets
+            tree_secondary += levels.secondary;
+            tree_lit += levels.lit;
         } else if (ds->has_ggx) {  // one thread per ray tree, depth first: replaces stages 1-5
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ref_order)
