@@ -741,6 +741,42 @@ k_bounces_fast(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t xcd_
 // `tally_on` = 0, and the grid is a wave per packet, which the hardware deals out as waves finish -- mirror
 // chains differ in length (22 616 packets at bounce 1, 2909 at bounce 2, 42 at bounce 6 in cornell_room) and a fixed
 // deal waits for its unluckiest wave (one blocking frame 0.900 -> 0.858 ms).
+// Ray trees level by level (see k_tree_count): where the rays of a level come from.  The rays of level L >= 1 are
+// never written anywhere: the lane that walks ray c makes it, in its first round, from the GGX hit its parent left
+// (the k-th reflected ray of ggx_mirror.rs:66-76; k = c minus the parent's first child), and notes the ray's tree
+// and path for the level below.  level = 0: not a level of ray trees, the rays lie in mirror-ray queue 1.
+struct TreeSpawn {
+    const uint32_t *parent, *base;       // per ray of this level: its parent in the level above; per parent: its first child
+    const double *p[3], *n[3], *in[3];   // the parents' GGX hits (RtBuffers::g_* of the level above)
+    const int32_t *shape, *tri, *mark;
+    const uint64_t *root_in, *path_in;   // per parent: its tree's frame-wide sample index, its ray's path (level >= 2)
+    uint64_t *root_out, *path_out;       // per ray of this level
+    uint32_t level;
+};
+
+__device__ __forceinline__ void tree_spawn_ray(const RtSceneView &S, const RtBatch &B, const TreeSpawn &T, uint32_t c, MirrorTmp &ray, int &depth) {
+    const uint32_t parent = T.parent[c], k = c - T.base[parent];
+    const int32_t mark = T.mark[parent];
+    const RtShader &sh = S.shaders[(uint32_t)mark >> 8];
+    const D3 p = D3{T.p[0][parent], T.p[1][parent], T.p[2][parent]};
+    const D3 n = D3{T.n[0][parent], T.n[1][parent], T.n[2][parent]};
+    const D3 incoming = D3{T.in[0][parent], T.in[1][parent], T.in[2][parent]};
+    const uint64_t root = T.level == 1u ? frame_sample(B, parent) : T.root_in[parent];
+    const uint64_t path = tree_child_path(T.level == 1u ? 0ull : T.path_in[parent], k);
+    ray.p = p;
+    ray.d = ggx_child_direction(n, incoming, sh.roughness, root, path, B.seed);
+    ray.sample = (int32_t)c;
+    ray.shape = T.shape[parent];
+    ray.tri = T.tri[parent];
+    double st;
+    ray.self_t = self_hit_f64(S, ray.shape, ray.p, ray.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(n, ray.d) > 0.0, false, st)
+                     ? (float)st
+                     : __builtin_inff();
+    depth = (mark & 0xff) + 1;
+    RT_STREAM_ST(T.root_out[c], root);
+    RT_STREAM_ST(T.path_out[c], path);
+}
+
 #define RT_BOUNCE_KEEP 17
 __device__ __forceinline__ void keep_ray(int32_t *keep, const D3 &o, const D3 &d) {
     const double v[6] = {o.x, o.y, o.z, d.x, d.y, d.z};
@@ -764,6 +800,7 @@ struct BouncePacketKernargs {
     RtIdOut ids;
     uint32_t n_samples;
     uint32_t tally_on;
+    TreeSpawn T;
 };
 typedef const __attribute__((address_space(4))) BouncePacketKernargs *BouncePacketKernargsPtr;
 // Waves per SIMD: the stage behind a mirror ray's hit is a chain of dependent loads with f64 arithmetic in between,
@@ -776,9 +813,10 @@ typedef const __attribute__((address_space(4))) BouncePacketKernargs *BouncePack
 #ifndef RT_BOUNCE_PACKET_RESIDENT
 #define RT_BOUNCE_PACKET_RESIDENT RT_BOUNCE_PACKET_WAVES  // waves per SIMD that the kernel's grid asks for
 #endif
-__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_PACKET_WAVES, RT_BOUNCE_PACKET_WAVES)))
-k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples, uint32_t tally_on) {
-    extern __shared__ int32_t lds[];
+// TREE: the rays are a level of ray trees and are made here (TreeSpawn); a kernel of its own, so that the code that
+// makes a ray (trigonometry in f64) costs the mirror bounces of every other scene neither registers nor scratch.
+template <bool TREE>
+__device__ __forceinline__ void bounces_packet_body(const RtSceneView &S, const RtBuffers &Q, uint32_t n_samples, uint32_t tally_on, int32_t *lds) {
     const BouncePacketKernargsPtr args = (BouncePacketKernargsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     int rows;
     {
@@ -827,15 +865,25 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
                 float t0 = -__builtin_inff();  // a slot without a ray: an empty search interval
                 int32_t shape0 = -1, org_shape = -1, org_tri = -1;
                 if (going) {
-                    if (b == 1) {
+                    if (TREE && b == 1) {  // a level of ray trees: the ray is made here
+                        MirrorTmp made;
+                        int depth;
+                        tree_spawn_ray(K.S, K.B, K.T, idx, made, depth);
+                        o = made.p;
+                        d = made.d;
+                        org_shape = made.shape;
+                        org_tri = made.tri;
+                        t0 = made.self_t;
+                        keep[12 * RT_PACKET_BLOCK] = made.sample;
+                        keep[13 * RT_PACKET_BLOCK] = depth;  // reflections in front of this ray
+                        keep_ray(keep, o, d);
+                    } else if (b == 1) {
                         queue_read_ray(K.Q, which, idx, o, d);
                         org_shape = K.Q.q_org_shape[which][idx];
                         org_tri = K.Q.q_org_tri[which][idx];
                         t0 = K.Q.q_self_t[which][idx];  // the origin primitive's own re-hit, or +inf
                         keep[12 * RT_PACKET_BLOCK] = K.Q.q_sample[which][idx];
-                        // reflections in front of this ray: one, or (a level of ray trees, whose rays start at different
-                        // depths) what the ray was spawned with
-                        keep[13 * RT_PACKET_BLOCK] = K.Q.n_depth != nullptr ? K.Q.n_depth[idx] : 1;
+                        keep[13 * RT_PACKET_BLOCK] = 1;  // reflections in front of this ray
                         keep_ray(keep, o, d);
                     } else {
                         kept_ray(keep, o, d);
@@ -897,6 +945,20 @@ k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_
         atomicAdd(&fresh(args).Q.counters[RT_CNT_RAYS0 + threadIdx.x + 1], tally[threadIdx.x]);
 }
 
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_PACKET_WAVES, RT_BOUNCE_PACKET_WAVES)))
+k_bounces_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples, uint32_t tally_on, TreeSpawn T) {
+    extern __shared__ int32_t lds[];
+    bounces_packet_body<false>(S, Q, n_samples, tally_on, lds);
+}
+#ifndef RT_BOUNCE_TREE_WAVES
+#define RT_BOUNCE_TREE_WAVES 4  // (128 registers, no scratch: ggx_scene 2.14 ms; 5 waves, 96 registers, 88 bytes of scratch: 2.35)
+#endif
+__global__ void __launch_bounds__(RT_PACKET_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_BOUNCE_TREE_WAVES, RT_BOUNCE_TREE_WAVES)))
+k_bounces_packet_tree(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32_t n_samples, uint32_t tally_on, TreeSpawn T) {
+    extern __shared__ int32_t lds[];
+    bounces_packet_body<true>(S, Q, n_samples, tally_on, lds);
+}
+
 // ---- scenes with a GGX shader: one thread walks its sample's whole ray tree (rt_tree.h).
 // The traversal stack lives in LDS like the per-lane kernels'; the tree's own stack of waiting
 // GGX hits is per-thread scratch memory.
@@ -925,17 +987,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_render_tree(RtSceneView S, RtBuffe
 // that the GGX hits of level L spawn -- go through the fast mode's stages as if they were a batch's samples:
 // packet walk, the stage behind it (mirror chains included), shadow packets and light sums, colour into the
 // ray's slot of the level's colour array.  A ray whose chain ends on a GGX surface leaves the hit in its slot
-// (shade_hit's RT_ACT_GGX); the kernels below number the next level's rays (count -> scan -> link), make them
-// (spawn), and when the deepest level is done add the children's colours up into their parents, level by level
-// upwards, in the order of the reference's loop (ggx_mirror.rs:66-93).  Against the depth-first walk of one
+// (shade_hit's RT_ACT_GGX); the kernels below number the next level's rays (count -> scan -> link), the lane that
+// walks a ray makes it from its parent's hit (tree_spawn_ray), and when the deepest level is done the children's
+// colours are added up into their parents, level by level upwards, in the order of the reference's loop
+// (ggx_mirror.rs:66-93).  Against the depth-first walk of one
 // lane per tree (k_render_tree) the rays of a level are coherent enough for packets, no lane waits for a
 // neighbour's deeper tree, and nothing lives in scratch memory.
 struct TreeLevelView {
     uint32_t *off, *chunk_base, *parent;
     uint32_t *base, *count;               // of the level that spawns
-    const uint64_t *root_in, *path_in;    // per node of the level that spawns (unused at level 0)
-    uint64_t *root_out, *path_out;        // per node of the level being made
-    int32_t *depth_out;
 };
 
 // One block per chunk of RT_LIT_CHUNK nodes: how many rays each node spawns (its shader's `samples` where its
@@ -997,8 +1057,14 @@ __global__ void __launch_bounds__(RT_LIT_THREADS) k_tree_scan(TreeLevelView T, u
 // One thread per node of the level that spawns: where its children start in the next level and how many they are
 // (kept per level for the sums on the way back up), and each child's parent.  `room`: nodes the next level can hold;
 // the host has checked the total against it before this launch.
-__global__ void __launch_bounds__(RT_BLOCK) k_tree_link(RtSceneView S, RtBuffers Q, TreeLevelView T, uint32_t n_nodes) {
+__global__ void __launch_bounds__(RT_BLOCK) k_tree_link(RtSceneView S, RtBuffers Q, TreeLevelView T, uint32_t n_nodes, uint32_t *next_queue_counts,
+                                                        uint32_t n_children) {
     const uint32_t node = blockIdx.x * RT_BLOCK + threadIdx.x;
+    // the stretches of the next level's queue (RtBuffers::mirror_counts of that level): its rays fill them without
+    // gaps (they are fewer than this level's nodes times the largest `samples`, far fewer than 1024 per node)
+    const uint32_t next_chunks = (n_children + RT_LIT_CHUNK - 1u) / RT_LIT_CHUNK;
+    for (uint32_t c = node; c < next_chunks; c += gridDim.x * RT_BLOCK)
+        next_queue_counts[c] = min(n_children - c * RT_LIT_CHUNK, (uint32_t)RT_LIT_CHUNK);
     if (node >= n_nodes) return;
     const int32_t mark = Q.g_mark[node];
     const uint32_t want = mark >= 0 ? S.shaders[(uint32_t)mark >> 8].samples : 0u;
@@ -1006,38 +1072,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_tree_link(RtSceneView S, RtBuffers
     T.base[node] = base;
     T.count[node] = want;
     for (uint32_t k = 0; k < want; ++k) T.parent[base + k] = node;
-}
-
-// One thread per ray of the level being made: the k-th reflected ray of its parent's GGX hit (ggx_mirror.rs:66-76),
-// into slot = its own number of mirror-ray queue 1, where k_bounces_packet takes a level's rays from.
-__global__ void __launch_bounds__(RT_BLOCK) k_tree_spawn(RtSceneView S, RtBuffers Q, RtBatch B, TreeLevelView T, uint32_t level, uint32_t n_children) {
-    const uint32_t c = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (c >= n_children) return;
-    const uint32_t parent = T.parent[c], k = c - T.base[parent];
-    const int32_t mark = Q.g_mark[parent];
-    const RtShader &sh = S.shaders[(uint32_t)mark >> 8];
-    const D3 p = D3{RT_STREAM_LD(Q.g_p[0][parent]), RT_STREAM_LD(Q.g_p[1][parent]), RT_STREAM_LD(Q.g_p[2][parent])};
-    const D3 n = D3{RT_STREAM_LD(Q.g_n[0][parent]), RT_STREAM_LD(Q.g_n[1][parent]), RT_STREAM_LD(Q.g_n[2][parent])};
-    const D3 incoming = D3{RT_STREAM_LD(Q.g_in[0][parent]), RT_STREAM_LD(Q.g_in[1][parent]), RT_STREAM_LD(Q.g_in[2][parent])};
-    const int32_t shape = Q.g_shape[parent], tri = Q.g_tri[parent];
-    const uint64_t root = level == 0u ? frame_sample(B, parent) : T.root_in[parent];
-    const uint64_t path = tree_child_path(level == 0u ? 0ull : T.path_in[parent], k);
-    MirrorTmp tmp;
-    tmp.p = p;
-    tmp.d = ggx_child_direction(n, incoming, sh.roughness, root, path, B.seed);
-    tmp.sample = (int32_t)c;
-    tmp.shape = shape;
-    tmp.tri = tri;
-    double st;
-    tmp.self_t = self_hit_f64(S, shape, tmp.p, tmp.d, RT_VERY_SMALL_NUMBER, (double)__builtin_inff(), dot(n, tmp.d) > 0.0, false, st)
-                     ? (float)st
-                     : __builtin_inff();
-    queue_write_ray(Q, 1, c, tmp);
-    T.root_out[c] = root;
-    T.path_out[c] = path;
-    T.depth_out[c] = (mark & 0xff) + 1;
-    // the queue's stretches (RtBuffers::mirror_counts): a level's rays fill them without gaps
-    if (c % RT_LIT_CHUNK == 0u) Q.mirror_counts[c / RT_LIT_CHUNK] = min(n_children - c, (uint32_t)RT_LIT_CHUNK);
 }
 
 // One thread per node of a level whose children are done: ggx_mirror.rs:89-93, the children's colours added up in
@@ -1440,21 +1474,22 @@ int ensure_tree_buffers(RtBackend *be, uint32_t capacity, int levels) {
         t.host_words = keep_words;
         t.copied = keep_event;
         const size_t cap = capacity;
-        for (int k = 0; k < 3; ++k) {
-            if (int rc = alloc_into(t.allocs, &t.g_p[k], cap)) return rc;
-            if (int rc = alloc_into(t.allocs, &t.g_n[k], cap)) return rc;
-            if (int rc = alloc_into(t.allocs, &t.g_in[k], cap)) return rc;
+        for (int w = 0; w < 2; ++w) {
+            for (int k = 0; k < 3; ++k) {
+                if (int rc = alloc_into(t.allocs, &t.g_p[w][k], cap)) return rc;
+                if (int rc = alloc_into(t.allocs, &t.g_n[w][k], cap)) return rc;
+                if (int rc = alloc_into(t.allocs, &t.g_in[w][k], cap)) return rc;
+            }
+            if (int rc = alloc_into(t.allocs, &t.g_shape[w], cap)) return rc;
+            if (int rc = alloc_into(t.allocs, &t.g_tri[w], cap)) return rc;
+            if (int rc = alloc_into(t.allocs, &t.g_mark[w], cap)) return rc;
         }
-        if (int rc = alloc_into(t.allocs, &t.g_shape, cap)) return rc;
-        if (int rc = alloc_into(t.allocs, &t.g_tri, cap)) return rc;
-        if (int rc = alloc_into(t.allocs, &t.g_mark, cap)) return rc;
         if (int rc = alloc_into(t.allocs, &t.off, cap)) return rc;
         if (int rc = alloc_into(t.allocs, &t.chunk_base, cap / RT_LIT_CHUNK + 2)) return rc;
         if (int rc = alloc_into(t.allocs, &t.parent, cap)) return rc;
         for (int w = 0; w < 2; ++w) {
             if (int rc = alloc_into(t.allocs, &t.root[w], cap)) return rc;
             if (int rc = alloc_into(t.allocs, &t.path[w], cap)) return rc;
-            if (int rc = alloc_into(t.allocs, &t.depth[w], cap)) return rc;
         }
         t.capacity = capacity;
     }
@@ -1630,12 +1665,6 @@ int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs
     const uint32_t room = Q.capacity;
     uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
                                Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
-    for (int k = 0; k < 3; ++k) {
-        Q.g_p[k] = tl.g_p[k];
-        Q.g_n[k] = tl.g_n[k];
-        Q.g_in[k] = tl.g_in[k];
-    }
-    Q.g_shape = tl.g_shape; Q.g_tri = tl.g_tri; Q.g_mark = tl.g_mark;
     std::vector<uint32_t> level_nodes;  // rays per level
     bool too_large = false;
     uint64_t batch_secondary = 0, batch_lit = 0;
@@ -1649,25 +1678,45 @@ int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs
         L.mirror_counts = L.block_counts + chunks;
         L.counters_next = sets[(level & 1) ^ 1];
         L.color = level == 0 ? Q.color : tl.color[(size_t)level];
-        L.n_depth = level == 0 ? nullptr : tl.depth[level & 1];
+        // where this level's rays leave their GGX hits, and (levels >= 1) the hits of the level above, which they are made from
+        const int mine = level & 1, above = mine ^ 1;
+        for (int k = 0; k < 3; ++k) {
+            L.g_p[k] = tl.g_p[mine][k];
+            L.g_n[k] = tl.g_n[mine][k];
+            L.g_in[k] = tl.g_in[mine][k];
+        }
+        L.g_shape = tl.g_shape[mine]; L.g_tri = tl.g_tri[mine]; L.g_mark = tl.g_mark[mine];
+        TreeSpawn from{};
+        if (level > 0) {
+            from.parent = tl.parent;
+            from.base = tl.base[(size_t)level - 1];
+            for (int k = 0; k < 3; ++k) {
+                from.p[k] = tl.g_p[above][k];
+                from.n[k] = tl.g_n[above][k];
+                from.in[k] = tl.g_in[above][k];
+            }
+            from.shape = tl.g_shape[above]; from.tri = tl.g_tri[above]; from.mark = tl.g_mark[above];
+            from.root_in = tl.root[above]; from.path_in = tl.path[above];
+            from.root_out = tl.root[mine]; from.path_out = tl.path[mine];
+            from.level = (uint32_t)level;
+        }
         const uint32_t grid_packets = (nodes + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
         const uint32_t grid_threads = (nodes + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, grid_threads / 256u));
         while ((xcd_chunk & (xcd_chunk - 1u)) != 0u) xcd_chunk &= xcd_chunk - 1u;
         const RtIdOut level_io = level == 0 ? io : RtIdOut{};
-        if (level == 0) {
-            RT_HIP(hipMemsetAsync(L.counters, 0, ((size_t)RT_CNT_SIZE + 2u * chunks) * sizeof(uint32_t), stream));
-        } else {
-            // (this level's counters were cleared before its rays were made: the spawn kernel has written the
-            // queue's stretch lengths into them)
-        }
-        RT_HIP(hipMemsetAsync(Q.g_mark, 0xff, (size_t)nodes * sizeof(int32_t), stream));
+        // (the counters of a level >= 1 were cleared before k_tree_link wrote its queue's stretch lengths into them)
+        if (level == 0) RT_HIP(hipMemsetAsync(L.counters, 0, ((size_t)RT_CNT_SIZE + 2u * chunks) * sizeof(uint32_t), stream));
+        RT_HIP(hipMemsetAsync(L.g_mark, 0xff, (size_t)nodes * sizeof(int32_t), stream));
         if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
         if (level == 0)
             hipLaunchKernelGGL(k_camera_shade_packet, dim3(grid_packets), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, L, B, level_io, nodes, xcd_chunk, 0u);
         if (level > 0 || ds->has_mirror) {
             const uint32_t gp = stats ? std::min<uint32_t>(grid_packets, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : grid_packets;
-            hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u);
+            if (level == 0)
+                hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u, from);
+            else
+                hipLaunchKernelGGL(k_bounces_packet_tree, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, L, B, level_io, nodes, stats ? 1u : 0u, from);
         }
         tm.end();
         level_nodes.push_back(nodes);
@@ -1676,9 +1725,6 @@ int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs
         TreeLevelView T{};
         T.off = tl.off; T.chunk_base = tl.chunk_base; T.parent = tl.parent;
         T.base = tl.base[(size_t)level]; T.count = tl.count[(size_t)level];
-        T.root_in = tl.root[level & 1]; T.path_in = tl.path[level & 1];
-        T.root_out = tl.root[(level & 1) ^ 1]; T.path_out = tl.path[(level & 1) ^ 1];
-        T.depth_out = tl.depth[(level & 1) ^ 1];
         if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
         hipLaunchKernelGGL(k_tree_count, dim3(chunks), dim3(RT_LIT_THREADS), 0, stream, S, L, T, nodes);
         hipLaunchKernelGGL(k_tree_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, T, chunks);
@@ -1711,16 +1757,12 @@ int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs
             too_large = true;
             break;
         }
-        // the next level's rays
-        RtBuffers N = Q;
+        // the next level: its counters, where each of its rays hangs, how long the stretches of its queue are
         const uint32_t next_chunks = (next_nodes + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
-        N.counters = sets[(level & 1) ^ 1];
-        N.block_counts = N.counters + RT_CNT_SIZE;
-        N.mirror_counts = N.block_counts + next_chunks;
-        RT_HIP(hipMemsetAsync(N.counters, 0, ((size_t)RT_CNT_SIZE + 2u * next_chunks) * sizeof(uint32_t), stream));
+        uint32_t *const next_counters = sets[(level & 1) ^ 1];
+        RT_HIP(hipMemsetAsync(next_counters, 0, ((size_t)RT_CNT_SIZE + 2u * next_chunks) * sizeof(uint32_t), stream));
         if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-        hipLaunchKernelGGL(k_tree_link, dim3(grid_threads), dim3(RT_BLOCK), 0, stream, S, L, T, nodes);
-        hipLaunchKernelGGL(k_tree_spawn, dim3((next_nodes + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, S, N, B, T, (uint32_t)level, next_nodes);
+        hipLaunchKernelGGL(k_tree_link, dim3(grid_threads), dim3(RT_BLOCK), 0, stream, S, L, T, nodes, next_counters + RT_CNT_SIZE + next_chunks, next_nodes);
         tm.end();
         nodes = next_nodes;
     }
@@ -2067,7 +2109,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                     // counts to the batch's counters once each.  Without: a wave per packet, dealt by the hardware
                     // as waves finish (mirror chains differ in length; a fixed deal waits for its unluckiest wave).
                     const uint32_t gp = stats ? std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : packet_grid;
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u);
+                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u, TreeSpawn{});
                 } else {
                     const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
                     hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);

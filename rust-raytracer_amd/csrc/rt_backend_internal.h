@@ -51,13 +51,14 @@ struct RtBackend {
     struct TreeLevels {
         std::vector<void *> allocs;
         uint32_t capacity = 0;
-        double *g_p[3] = {}, *g_n[3] = {}, *g_in[3] = {};
-        int32_t *g_shape = nullptr, *g_tri = nullptr, *g_mark = nullptr;
+        // the GGX hits that the rays of a level leave (RtBuffers::g_*), two sets: a level's rays are made from the
+        // hits of the level above while they leave their own
+        double *g_p[2][3] = {}, *g_n[2][3] = {}, *g_in[2][3] = {};
+        int32_t *g_shape[2] = {}, *g_tri[2] = {}, *g_mark[2] = {};
         uint32_t *off = nullptr;         // [capacity] where a node's children start inside its chunk's run of children
         uint32_t *chunk_base = nullptr;  // [chunks + 1] children per chunk of nodes, then their exclusive sums; last: all
         uint32_t *parent = nullptr;      // [capacity] the node that each node of the NEXT level hangs under
         uint64_t *root[2] = {}, *path[2] = {};  // [capacity] per node: its tree's frame-wide sample index, its ray's path
-        int32_t *depth[2] = {};          // [capacity] per node: reflections in front of its ray
         // per level (level 0 is the batch's samples, whose colours are the batch's own colour array)
         std::vector<float *> color;      // [3 * capacity]
         std::vector<uint32_t *> base, count;  // [capacity] children of each node: where they start in the next level, how many

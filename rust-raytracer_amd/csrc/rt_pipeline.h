@@ -91,7 +91,6 @@ struct RtBuffers {
     int32_t *g_shape;
     int32_t *g_tri;
     int32_t *g_mark;         // (shader index << 8) | depth of the hit; < 0: the slot's ray did not end on a GGX surface
-    const int32_t *n_depth;  // levels >= 1: the depth (reflections so far) of each slot's ray as it was spawned; null at level 0
 };
 
 #define RT_LIT_CHUNK 1024u

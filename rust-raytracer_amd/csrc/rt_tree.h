@@ -50,7 +50,7 @@ RT_HD D3 sample_ggx(const D3 &normal, double alpha, double u1, double u2) {
     const double r = sqrt(alpha * alpha * u2 / (1.0 - u2));
     const double cos_theta = 1.0 / sqrt(1.0 + r * r), sin_theta = r * cos_theta;
     double sin_phi, cos_phi;
-    sincos(phi, &sin_phi, &cos_phi);
+    sincos(phi, &sin_phi, &cos_phi);  // (sincospi(2 u1) on the device, whose argument reduction is exact and short: no faster)
     const double x = sin_theta * cos_phi, y = sin_theta * sin_phi, z = cos_theta;
     D3 tangent, bitangent;
     create_coordinate_system(normal, tangent, bitangent);
