@@ -6,7 +6,7 @@ OUT=gpurun_out/trace_ggx
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 tools/ggx_timing.py trace > $OUT/run.txt 2>&1 || { tail -5 $OUT/run.txt; exit 1; }
-python3 - $OUT <<'PY'
+python3 - $OUT <<'PY' | tee $OUT/launches.txt
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):

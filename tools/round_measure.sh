@@ -17,7 +17,8 @@ for w in $WHAT; do
       cat gpurun_out/$TAG/bench_all.log
       timeout -k 10 300 python3 bench.py --steps 200 --warmup 5 > gpurun_out/$TAG/bench200.json 2> gpurun_out/$TAG/bench200.err || exit 1
       timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/$TAG/bench20.json 2> gpurun_out/$TAG/bench20.err || exit 1
-      python3 tools/ggx_timing.py 2>/dev/null | tee gpurun_out/$TAG/ggx.log ;;
+      python3 tools/ggx_timing.py 2>/dev/null | tee gpurun_out/$TAG/ggx.log
+      tools/ggx_trace.sh > gpurun_out/$TAG/ggx_trace.log 2>&1 || { echo "ggx trace failed"; tail -5 gpurun_out/$TAG/ggx_trace.log; exit 1; } ;;
     parts)
       GPU_MAX_HW_QUEUES=32 timeout -k 10 300 python3 tools/part_timing.py bunny 200 8 2>/dev/null | tee gpurun_out/$TAG/part_timing_8.log
       RT_SPAN=0 GPU_MAX_HW_QUEUES=32 timeout -k 10 300 python3 tools/part_timing.py bunny 200 8 2>/dev/null | tee gpurun_out/$TAG/part_timing_8_span.log
