@@ -504,6 +504,9 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
             }
         }
     }
+#ifdef RT_WAVE_TIMELINE
+    const unsigned long long walked = wall_clock64();
+#endif
     const FusedKernargs &K = fresh(args);
     if (!ok) *K.Q.overflow = 1;
     const uint32_t idx = opaque(idx0);
@@ -522,6 +525,9 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         accumulate_masked<true>(K.S, K.Q, sample, shape, p, *hidden_slot);  // fast mode only
     }
     RT_WAVE_LOG(gridDim.x + blockIdx.x);
+#ifdef RT_WAVE_TIMELINE
+    wave_log(15u * gridDim.x + blockIdx.x, walked);
+#endif
 }
 
 // Camera rays AND the stage behind them in one kernel (fast mode): the wave walks the tree with its 64 camera
@@ -591,6 +597,9 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         st[0].org_tri = -1;
     }
     const bool ok = packet_traverse<false, 1>(S, st, closest_tmin(0), lds, rows - 1);  // (the walk's fields of S stay in registers)
+#ifdef RT_WAVE_TIMELINE
+    const unsigned long long walked = wall_clock64();  // (second record of the wave: from the end of the walk to the end)
+#endif
     const CameraKernargs &K = fresh(args);
     if (!ok) *K.Q.overflow = 1;
     const uint32_t idx = opaque(idx0);
@@ -618,6 +627,9 @@ k_camera_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     // listed at once in the chunk's stretch of the lit list, at the place the count gives.
     wave_list_lit(K.Q, K.B.direct_lit != 0u, __ballot(act == RT_ACT_LIT), act == RT_ACT_LIT, idx / RT_LIT_CHUNK, idx);
     RT_WAVE_LOG(blockIdx.x);
+#ifdef RT_WAVE_TIMELINE
+    wave_log(14u * gridDim.x + blockIdx.x, walked);
+#endif
 }
 
 // ALL mirror bounces in one kernel (fast mode): a lane takes a ray from the first bounce's queue, follows it
