@@ -1260,20 +1260,20 @@ __global__ void __launch_bounds__(RT_RESOLVE_BLOCK) k_resolve(RtBuffers Q, RtBat
             uint32_t px = lane / per_px, el = lane - px * per_px;
             const uint32_t last_px = B.n_pixels - 1u;  // a pixel past the end reads the last one's samples; nobody adds them up
             if (per_px == RT_RESOLVE_ROW) {
-                // a full round: all loads first, then all stores, so that the loads are in flight together
+                // a full round: all loads first, then all stores, so that the loads are in flight together.  (Float
+                // f = lane + 64 m of the round lies at px * RT_RESOLVE_ROW + el = f of the table: no index to keep per
+                // load, which had cost 27 registers and, at 148 in all, left three waves per SIMD to hide HBM behind.)
                 float v[RT_RESOLVE_ROW];
-                uint32_t at[RT_RESOLVE_ROW];
 #pragma unroll
                 for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) {
                     const uint32_t src_px = min(group * 64u + px, last_px);
                     v[m] = RT_STREAM_LD(Q.color[((size_t)src_px * spp + k0) * 3 + el]);
-                    at[m] = px * RT_RESOLVE_ROW + el;
                     px += 64u / RT_RESOLVE_ROW;
                     el += 64u % RT_RESOLVE_ROW;
                     if (el >= RT_RESOLVE_ROW) { el -= RT_RESOLVE_ROW; px += 1; }
                 }
 #pragma unroll
-                for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) st[at[m]] = v[m];
+                for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) st[lane + 64u * m] = v[m];
             } else {
                 for (uint32_t m = 0; m < per_px; ++m) {
                     const uint32_t src_px = min(group * 64u + px, last_px);
