@@ -172,7 +172,8 @@ typedef struct RtRenderArgs {
      * enqueues. */
     void (*progress)(uint64_t pixels_done, uint64_t pixels_total, void *user);
     void *progress_user;
-    /* Tuning; 0 = the library's choice everywhere.  None of them changes a pixel.
+    /* Tuning; 0 = the library's choice everywhere.  None of them changes a pixel (RT_RENDER_TREE_DEPTH_FIRST, for
+     * scenes with a GGXMirror shader, changes colours in the last places of an f32: see there).
      *  batch_samples  most samples (pixels x rays per pixel) worked on at a time; a larger frame is
      *                 rendered in several batches of whole tiles (0 -> 32 Mi, about 8.5 GB of work buffers)
      *  xcd_chunk      consecutive 256-sample blocks handed to one XCD (one L2) at a time (rounded down to a power of two)
