@@ -566,9 +566,12 @@ RT_HD void trace_shadow_fast_body(const RtSceneView &S, const RtBuffers &Q, uint
 // `p`: the hit point as the lit table holds it (the caller has it at hand).
 template <bool F32>
 RT_HD void accumulate_masked(const RtSceneView &S, const RtBuffers &Q, uint32_t sample, int32_t shape, const D3 &p, uint32_t blocked) {
-    const RtShader &sh = S.shaders[S.shapes[shape].shader];
+    // The view direction is asked for whether or not the shader turns out to look at it (only a Blinn-Phong hit has
+    // stored one; what lies in a Lambertian hit's slot is never used): asked for once the shader's type is known, it
+    // was a fourth memory round trip in a row -- list entry, shape, shader, direction -- at the end of every wave.
     const D3 n = lit_load_vec(Q.l_n, sample, F32);
-    const D3 d = sh.type == RT_SHADER_BLINN_PHONG ? lit_load_vec(Q.l_d, sample, F32) : D3{0.0, 0.0, -1.0};
+    const D3 d = lit_load_vec(Q.l_d, sample, F32);
+    const RtShader &sh = S.shaders[S.shapes[shape].shader];
     ColorF color = {0.0f, 0.0f, 0.0f};
     int slot = 0;
     for (int li = 0; li < S.n_lights; ++li) {
