@@ -443,7 +443,11 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         shadows = !K.S.disable_shadows;
     }
     RT_WAVE_T0();
-    uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows)) + threadIdx.x;  // behind the walk's LDS
+    // One word per lane behind the walk's LDS, bit k = point light k is hidden from the lane's hit.  It starts as the
+    // bits of the lights that the hit's own primitive hides (the f64 test of the stage that found the hit; all ones for
+    // a slot without a hit, which traces nothing): light k's turn reads bit k before anything but that test can have
+    // set it, and sets it if the walk finds a blocker.
+    uint32_t *hidden_slot = reinterpret_cast<uint32_t *>(lds + rt_packet_lds_dwords(rows)) + threadIdx.x;
     *hidden_slot = 0u;
     // What every light's shadow ray needs of the lane's lit hit -- the point, the primitive it lies on, the lights that
     // primitive hides by itself -- is fetched from the lit table ONCE and waits in LDS, three pairs per lane behind the
@@ -466,8 +470,9 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
             pz = RT_STREAM_LD(reinterpret_cast<const float *>(K.Q.l_p[2])[sample]);
         }
         rec[0 * RT_PACKET_BLOCK] = rt_pair(px, py);
-        rec[1 * RT_PACKET_BLOCK] = rt_pair(pz, rt_as_float((int32_t)self_mask));
+        rec[1 * RT_PACKET_BLOCK] = rt_pair(pz, rt_as_float((int32_t)sample0));  // (the list entry: not fetched again at the end)
         rec[2 * RT_PACKET_BLOCK] = rt_pair(rt_as_float(org_shape), rt_as_float(org_tri));
+        *hidden_slot = self_mask;
     }
     bool ok = true;
     if (shadows) {
@@ -479,7 +484,7 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
                 D3 o = D3{0.0, 0.0, 0.0}, d = D3{0.0, 0.0, -1.0};
                 const rt_f2 r0 = rec[0 * RT_PACKET_BLOCK], r1 = rec[1 * RT_PACKET_BLOCK], r2 = rec[2 * RT_PACKET_BLOCK];
                 const int32_t org_shape = rt_as_int(r2.x), org_tri = rt_as_int(r2.y);
-                self = (((uint32_t)rt_as_int(r1.y) >> ls) & 1u) != 0u;
+                self = ((*hidden_slot >> ls) & 1u) != 0u;
                 const bool trace = !self;
                 if (trace) {
                     o = D3{(double)r0.x, (double)r0.y, (double)r1.x};
@@ -493,10 +498,10 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
                 st[0].org_tri = org_tri;
             }
             ok = packet_traverse<true, 1>(S, st, (float)RT_VERY_SMALL_NUMBER, lds, rows - 1) && ok;  // (the walk's fields of S stay in registers)
-            if (live && (st[0].shape >= 0 || self)) *hidden_slot |= 1u << ls;
+            if (live && st[0].shape >= 0) *hidden_slot |= 1u << ls;
             if (want_ids && live) {
                 const FusedKernargs &K = fresh(args);
-                const uint32_t sample = K.Q.lit_list[opaque(idx0)];
+                const uint32_t sample = (uint32_t)rt_as_int(rec[1 * RT_PACKET_BLOCK].y);
                 const size_t at = global_sample(K.B, sample) * (size_t)n_point_lights + (size_t)ls;
                 const int32_t blocker = self ? RT_STREAM_LD(K.Q.l_shape[sample]) : st[0].shape;
                 if (K.ids.shadow_shape) K.ids.shadow_shape[at] = blocker;
@@ -511,14 +516,16 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
     if (!ok) *K.Q.overflow = 1;
     const uint32_t idx = opaque(idx0);
     if (idx < count) {
-        const uint32_t sample = K.Q.lit_list[idx];
+        uint32_t sample;
         D3 p;
         int32_t shape;
-        if (shadows) {  // point and primitive wait in LDS
+        if (shadows) {  // list entry, point and primitive wait in LDS
             const rt_f2 r0 = rec[0 * RT_PACKET_BLOCK], r1 = rec[1 * RT_PACKET_BLOCK], r2 = rec[2 * RT_PACKET_BLOCK];
+            sample = (uint32_t)rt_as_int(r1.y);
             p = D3{(double)r0.x, (double)r0.y, (double)r1.x};
             shape = rt_as_int(r2.x);
         } else {
+            sample = K.Q.lit_list[idx];
             p = lit_load_vec(K.Q.l_p, sample, true);
             shape = RT_STREAM_LD(K.Q.l_shape[sample]);
         }
