@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RT_HIP_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "librt_hip_timeline.so")
+os.environ.setdefault("RT_HIP_LIB", os.path.join(ROOT, "rust-raytracer_amd", "csrc", "librt_hip_timeline.so"))
 
 
 def describe(name, t0, t1, slots):
