@@ -259,16 +259,19 @@ class ManyGpus(Frames):
         # A backend caches the tile list of the parts it renders, so each flight keeps its parts: flight b renders the
         # frames k with (k div SPAN) = b (mod FLIGHTS), which start at the same part on this rank when N divides
         # SPAN * FLIGHTS; otherwise the parts stay where they are, one per set of launches.
-        span = int(os.environ.get("RT_BENCH_SPAN", "0")) or max(1, world // 4)
-        if (self.slots != 1 or GROUP % span != 0 or world % span != 0  # (the blocks of consecutive frames are neighbours only with
-                or (flights * span) % world != 0 or ctx.part0_weight != 0):  # one frame per root and group; a span's parts differ, so they rotate)
+        # The blocks of consecutive frames lie `slots` blocks apart in the send buffer ([root position][slot]); a span
+        # never straddles the end of a round of roots because it divides the number of ranks.
+        span = int(os.environ.get("RT_BENCH_SPAN", "0")) or (max(2, world // 4) if world >= 4 else 1)
+        if (GROUP % span != 0 or world % span != 0 or (flights * span) % world != 0  # (a span's parts differ, so they rotate)
+                or ctx.part0_weight != 0):
             span = 1
         self.span = span
         self.rotate = world > 1 and (flights * span) % world == 0 and ctx.part0_weight == 0
-        self.flight_args = [self.args(part=((rank + span * b) % world if self.rotate else rank, world), part0_weight=ctx.part0_weight,
-                                      part_span=span if span > 1 else 0) for b in range(flights)]
         self.tiles_total, self.tiles_owned, self.stride = self.dev.partition_info(self.args(part=(rank, world), part0_weight=ctx.part0_weight))
         self.part_floats = self.stride * self.tile * self.tile * 3
+        self.flight_args = [self.args(part=((rank + span * b) % world if self.rotate else rank, world), part0_weight=ctx.part0_weight,
+                                      part_span=span if span > 1 else 0,
+                                      part_span_pitch_floats=self.slots * self.part_floats if span > 1 else 0) for b in range(flights)]
         pf, S = self.part_floats, self.slots
         self.part = [torch.zeros(world * S * pf, dtype=torch.float32, device="cuda") for _ in range(2)]
         self.gathered = [torch.zeros(world * S * pf, dtype=torch.float32, device="cuda") for _ in range(2)]
