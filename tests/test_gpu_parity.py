@@ -848,6 +848,37 @@ def test_ggx_level_by_level_and_depth_first_agree(rt, backend):
     dev.close()
 
 
+def test_ggx_through_the_other_entry_points(rt, scene_path):
+    """A scene with ray trees through rt_render_multi (host threads, one per part, each waiting between the levels of
+    its own part), rt_render_async and rt_render_device: the frame of the plain rt_render, bit for bit."""
+    import torch
+
+    scene = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=128, image_height=96, recursion_depth=3)
+    backends = [rt.Backend(0) for _ in range(3)]
+    devs = [b.upload(scene) for b in backends]
+    whole = devs[0].render(2, seed=11, want_stats=False)[0].pixels.copy()
+    multi = rt.Multi(devs)
+    fb, stats = multi.render(devs[0].render_args(2, seed=11, tile=(16, 16)))
+    assert np.array_equal(fb, whole)
+    assert stats.secondary_rays > 3 * 128 * 96
+    multi.close()
+    pinned = rt.HostBuffer((96, 128, 3))
+    devs[1].render_async(devs[1].render_args(2, seed=11), pinned)
+    backends[1].sync()
+    assert np.array_equal(pinned.array, whole)
+    on_device = torch.zeros(96 * 128 * 3, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    devs[2].render_device(devs[2].render_args(2, seed=11), on_device.data_ptr(), stream=side.cuda_stream)
+    backends[2].sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(on_device.cpu().numpy().reshape(96, 128, 3), whole)
+    pinned.close()
+    for d in devs:
+        d.close()
+    for b in backends:
+        b.close()
+
+
 def test_ggx_matches_committed_fixture(rt, backend):
     g = np.load(os.path.join(GOLDEN, "render_ggx_scene.npz"))
     scene = rt.parse_scene(edge_scenes.ggx_scene(), "", image_width=64, image_height=48, recursion_depth=3)
