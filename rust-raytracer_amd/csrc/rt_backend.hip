@@ -475,6 +475,9 @@ k_shadow_shade_packet(RtSceneView S, RtBuffers Q, RtBatch B, RtIdOut ids, uint32
         *hidden_slot = self_mask;
     }
     bool ok = true;
+#ifdef RT_WAVE_TIMELINE
+    wave_log(16u * gridDim.x + blockIdx.x, wave_t0);  // (third record: the wave's way in, up to its first walk)
+#endif
     if (shadows) {
         for (int ls = 0; ls < n_point_lights; ++ls) {
             FastTrav st[1];

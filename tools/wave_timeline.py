@@ -61,7 +61,7 @@ def main():
     a = dev.render_args(n, tile=(tile, tile), part=(part, parts))
     _, owned, stride = dev.partition_info(a)
     packets = -(-owned * tile * tile * n * n // 64)
-    log = torch.zeros(32 * packets + 64, dtype=torch.int64, device="cuda")  # camera, shadow, 6 bounces x (walk, shade), what follows the walks
+    log = torch.zeros(34 * packets + 64, dtype=torch.int64, device="cuda")  # camera, shadow, 6 bounces x (walk, shade), what follows the walks
     fb = torch.zeros(W * H * 3 + tile * tile * 3 * 700, dtype=torch.float32, device="cuda")
     L = rt.lib()
     L.rt_debug_wave_log.argtypes = [C.c_void_p]
@@ -92,6 +92,11 @@ def main():
             back = (after[live, 1] - after[live, 0]) * 10 / 1e3
             print(f"{name}: from the wave's start to the end of its walk(s) us: median {np.median(front):.1f} mean {front.mean():.1f} p90 {np.percentile(front, 90):.1f}; "
                   f"what follows (the stage behind the hits / the light sums): median {np.median(back):.1f} mean {back.mean():.1f} p90 {np.percentile(back, 90):.1f}")
+    head = v[32 * packets:34 * packets].reshape(-1, 2)
+    live = (head[:, 1] > 0) & (sh[:, 1] > 0)
+    if live.any():
+        way_in = (head[live, 1] - head[live, 0]) * 10 / 1e3
+        print(f"shadow kernel: the way in (chunk count, list entry, lit record into LDS) us: median {np.median(way_in):.1f} mean {way_in.mean():.1f} p90 {np.percentile(way_in, 90):.1f}")
     bo = v[4 * packets:28 * packets].reshape(packets, 6, 2, 2)  # [packet][bounce][walk / shade][start, end]
     if (bo[:, :, 0, 1] > 0).any():
         for b in range(6):
