@@ -1316,6 +1316,59 @@ __global__ void __launch_bounds__(RT_RESOLVE_BLOCK) k_resolve(RtBuffers Q, RtBat
     }
 }
 
+// The same for more than RT_RESOLVE_ROUND samples per pixel, as long as two pixels' samples fit the table
+// (rt_resolve_by_pixels): WHOLE pixels per round, as many as fit.  The round's floats are then one contiguous piece of
+// memory, read line by line; in rounds of RT_RESOLVE_ROUND samples a pixel's piece is 108 bytes out of every 12 * spp,
+// which touches every cache line twice with loads that are told not to keep it.  A lane per (pixel, channel) then adds
+// up its row in sample order: the same sums, bit for bit.  (A kernel of its own: its loop bodies cost k_resolve, which
+// every 9-rays-per-pixel frame runs, two waves per SIMD.)
+inline bool rt_resolve_by_pixels(uint32_t spp) { return 3u * spp > RT_RESOLVE_ROW && ((3u * spp) | 1u) * 2u <= 64u * RT_RESOLVE_ROW; }
+__global__ void __launch_bounds__(RT_RESOLVE_BLOCK) k_resolve_pixels(RtBuffers Q, RtBatch B, float *fb) {
+    __shared__ float st[64 * RT_RESOLVE_ROW];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t spp = B.n * B.n;
+    const uint32_t n_groups = (B.n_pixels + 63u) / 64u;
+    const float div = (float)(uint16_t)(B.n * B.n);
+    const uint32_t row = 3u * spp;
+    {
+        const uint32_t pitch = row | 1u;  // odd: the lanes that add up different pixels' rows start in different banks
+        const uint32_t per_round = min(64u, (64u * RT_RESOLVE_ROW) / pitch);
+        const size_t all_floats = (size_t)B.n_pixels * row;
+        const uint32_t step_px = 64u / row, step_el = 64u % row;
+        for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+            for (uint32_t p0 = 0; p0 < 64u; p0 += per_round) {
+                const uint32_t n_px = min(per_round, 64u - p0), floats = n_px * row;
+                const size_t base = ((size_t)group * 64u + p0) * row;
+                float v[RT_RESOLVE_ROW];
+#pragma unroll
+                for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) {  // 64 * RT_RESOLVE_ROW >= floats: every float of the round has a load
+                    const uint32_t f = lane + 64u * m;
+                    v[m] = f < floats ? RT_STREAM_LD(Q.color[min(base + f, all_floats - 1u)]) : 0.0f;
+                }
+                uint32_t px = lane / row, el = lane - px * row;
+#pragma unroll
+                for (uint32_t m = 0; m < RT_RESOLVE_ROW; ++m) {
+                    if (lane + 64u * m < floats) st[px * pitch + el] = v[m];
+                    px += step_px;
+                    el += step_el;
+                    if (el >= row) { el -= row; px += 1; }
+                }
+                __syncthreads();
+                for (uint32_t u = lane; u < n_px * 3u; u += 64u) {  // (pixel, channel) pairs of the round
+                    const uint32_t q = u / 3u, c = u - q * 3u;
+                    const float *at = st + q * pitch + c;
+                    float acc = 0.0f;
+                    for (uint32_t k = 0; k < spp; ++k) acc += at[3u * k];  // p-major, q-minor: sample k = p*n + q
+                    const uint32_t lp = group * 64u + p0 + q;
+                    float *out;
+                    if (lp < B.n_pixels && resolve_address(B, lp, fb, out)) out[c] = acc / div;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_fill_i32(int32_t *p, size_t n, int32_t v) {
     for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK) p[i] = v;
 }
@@ -2200,8 +2253,11 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         }
         }
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-        hipLaunchKernelGGL(k_resolve, dim3((uint32_t)std::min<uint64_t>(((uint64_t)B.n_pixels + 63u) / 64u, 4u * RT_MAX_GRID)), dim3(RT_RESOLVE_BLOCK), 0,
-                           stream, Q, B, fb_dev);
+        {
+            const dim3 resolve_grid((uint32_t)std::min<uint64_t>(((uint64_t)B.n_pixels + 63u) / 64u, 4u * RT_MAX_GRID));
+            if (rt_resolve_by_pixels(spp)) hipLaunchKernelGGL(k_resolve_pixels, resolve_grid, dim3(RT_RESOLVE_BLOCK), 0, stream, Q, B, fb_dev);
+            else hipLaunchKernelGGL(k_resolve, resolve_grid, dim3(RT_RESOLVE_BLOCK), 0, stream, Q, B, fb_dev);
+        }
         tm.end();
 
         if (wait_batches) {

@@ -848,6 +848,25 @@ def test_ggx_level_by_level_and_depth_first_agree(rt, backend):
     dev.close()
 
 
+@pytest.mark.parametrize("n", [4, 6, 10, 17])
+def test_resolve_with_many_samples_per_pixel(rt, backend, scene_path, n):
+    """The per-pixel sum (render.rs:76-78) for more samples per pixel than the resolve kernel's rounds of nine: 16 and
+    36 and 100 go through the kernel that stages whole pixels, 289 (two pixels' samples do not fit its table) through
+    the rounds; an odd frame size leaves ragged groups of pixels.  Against the oracle, and as parts against the whole."""
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=70, image_height=45, recursion_depth=3)
+    dev = backend.upload(scene)
+    fb, _, _ = dev.render(n, want_stats=False)
+    ref_fb, _, _ = oracle_lib.render(scene, n, want_ids=False)
+    m = parity.image_metrics(fb.pixels, ref_fb)
+    assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, m
+    whole = np.zeros_like(fb.pixels)
+    for p in range(2):
+        part, _, _ = dev.render(n, tile=(16, 16), part=(p, 2), want_stats=False)
+        whole += part.pixels
+    assert np.array_equal(whole, fb.pixels)
+    dev.close()
+
+
 def test_ggx_through_the_other_entry_points(rt, scene_path):
     """A scene with ray trees through rt_render_multi (host threads, one per part, each waiting between the levels of
     its own part), rt_render_async and rt_render_device: the frame of the plain rt_render, bit for bit."""
