@@ -645,9 +645,16 @@ def main():
             for _ in range(5):
                 run.dev.render(run.n, mode=rt.RT_MODE_REFERENCE_ORDER, tile=(run.tile, run.tile), want_stats=False, out=run.host[0].array)
             extra["value_reference_order"] = rays_per_frame_local * 5 / (time.perf_counter() - t0)
+            # ... and in the fast mode itself with RT_RENDER_CLOSEST_BLOCKERS (packets on the mode's own trees, every shadow
+            # ray to its closest blocker): the same pixels, blocker ids comparable one to one
+            t0 = time.perf_counter()
+            for _ in range(5):
+                run.dev.render(run.n, tile=(run.tile, run.tile), want_stats=False, out=run.host[0].array, flags=rt.RT_RENDER_CLOSEST_BLOCKERS)
+            extra["value_closest_blockers"] = rays_per_frame_local * 5 / (time.perf_counter() - t0)
             extra["parity_mode_note"] = ("shadow rays are checked on the occlusion bit in this mode (fast: any-hit); blocker shape and triangle "
-                                         "ids are checked in reference-order mode (closest blocker, light/point.rs:35), which renders this "
-                                         f"frame at {extra['value_reference_order'] / 1e9:.2f} Grays/s (5 blocking frames, same run)")
+                                         "ids are checked (closest blocker, light/point.rs:35) in the fast mode with RT_RENDER_CLOSEST_BLOCKERS, "
+                                         f"which renders this frame at {extra['value_closest_blockers'] / 1e9:.2f} Grays/s, and in reference-order "
+                                         f"mode at {extra['value_reference_order'] / 1e9:.2f} Grays/s (5 blocking frames each, same run)")
 
     # Outside the timed region: the gathered frame must be bit-identical with the same frame rendered
     # whole (static tile map, ordered per-pixel sums).  Every rank that was a root checks the newest

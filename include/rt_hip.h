@@ -218,6 +218,11 @@ enum {
     RT_RENDER_UNFUSED_CAMERA = 8,   /* RT_MODE_FAST: the camera rays and the stage that decides what happens to their
                                        hits as two launches (the hit records go through memory) instead of one, and
                                        likewise two launches per mirror bounce instead of one for all bounces */
+    RT_RENDER_CLOSEST_BLOCKERS = 32, /* RT_MODE_FAST: shadow rays run to the CLOSEST blocker as light/point.rs:35 does (the
+                                       mode's own shadow rays stop at the first one they find), through the separate
+                                       shadow kernel: RtRayIds.shadow_shape / shadow_tri then compare with the reference's
+                                       one to one, as they do in RT_MODE_REFERENCE_ORDER, at several times that mode's
+                                       speed.  Pixels are the same as without it */
     RT_RENDER_TREE_DEPTH_FIRST = 16 /* scenes with a GGXMirror shader: one thread walks a sample's whole ray tree, depth
                                        first.  Without it RT_MODE_FAST traces the trees level by level through the
                                        packet kernels, four times as fast, but every call -- the enqueue-only ones

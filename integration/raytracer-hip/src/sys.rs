@@ -45,6 +45,7 @@ pub const RT_RENDER_ROW_MAJOR_PIXELS: u32 = 2;
 pub const RT_RENDER_UNFUSED_SHADOWS: u32 = 4;
 pub const RT_RENDER_UNFUSED_CAMERA: u32 = 8;
 pub const RT_RENDER_TREE_DEPTH_FIRST: u32 = 16;
+pub const RT_RENDER_CLOSEST_BLOCKERS: u32 = 32;
 
 pub const RT_UPLOAD_REFERENCE_MESH_TREES: u32 = 1;
 

@@ -42,6 +42,7 @@ RT_RENDER_ROW_MAJOR_PIXELS = 2
 RT_RENDER_UNFUSED_SHADOWS = 4
 RT_RENDER_UNFUSED_CAMERA = 8
 RT_RENDER_TREE_DEPTH_FIRST = 16
+RT_RENDER_CLOSEST_BLOCKERS = 32
 RT_UPLOAD_REFERENCE_MESH_TREES = 1
 RT_COMM_ID_BYTES = 128
 RT_STATIC_SCRATCH_BYTES = 64 << 20

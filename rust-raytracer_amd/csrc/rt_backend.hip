@@ -326,7 +326,7 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
         // instead of a memset (two more launches in front of every frame).  n_clear = 0: nothing to clear.
         if (KIND == 0)
             for (uint32_t i = blockIdx.x * RT_PACKET_BLOCK + threadIdx.x; i < K.n_clear; i += gridDim.x * RT_PACKET_BLOCK) K.Q.counters_next[i] = 0u;
-        count = KIND == 1 ? K.Q.counters[RT_CNT_LIT] : K.n_samples;
+        count = KIND != 0 ? K.Q.counters[RT_CNT_LIT] : K.n_samples;
         const uint32_t n_blocks = (count + per_block - 1) / per_block;  // blocks that have work; the rest leave
         if (blockIdx.x >= n_blocks) return;
         base = xcd_chunked_block(blockIdx.x, n_blocks, K.xcd_chunk * RT_BLOCK / per_block) * per_block + threadIdx.x;
@@ -346,6 +346,9 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
             if (KIND == 1) {
                 sample[k] = K.Q.lit_list[idx];
                 live[k] = shadow_setup_lit(K.S, K.Q, blockIdx.y, sample[k], r);
+            } else if (KIND == 2) {  // shadow rays that run to the CLOSEST blocker (light/point.rs:35), the own primitive's re-hit as their bound
+                sample[k] = K.Q.lit_list[idx];
+                live[k] = shadow_setup<false>(K.S, K.Q, blockIdx.y, sample[k], r);
             } else {
                 live[k] = closest_setup(K.S, K.Q, K.B, 0, idx, r);
             }
@@ -364,14 +367,14 @@ k_trace_packet(RtSceneView S, RtBuffers Q, RtBatch B, uint32_t n_samples, uint32
         st[k].org_shape = r.org_shape;
         st[k].org_tri = r.org_tri;
     }
-    const float tmin = KIND == 1 ? (float)RT_VERY_SMALL_NUMBER : closest_tmin(0);
+    const float tmin = KIND != 0 ? (float)RT_VERY_SMALL_NUMBER : closest_tmin(0);
     const bool ok = packet_traverse<KIND == 1, R>(S, st, tmin, lds, rows - 1);  // (the walk's fields of S stay in registers)
     const PacketKernargs &K = fresh(args);
     if (!ok) *K.Q.overflow = 1;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (!live[k]) continue;
-        if (KIND == 1) shadow_store(K.Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
+        if (KIND != 0) shadow_store(K.Q, blockIdx.y, sample[k], st[k].shape, st[k].tri);
         else closest_store(K.Q, base + (uint32_t)k * RT_PACKET_BLOCK, st[k].t, st[k].shape, st[k].tri);
     }
 }
@@ -1997,7 +2000,7 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // samples, so a batch of camera rays is sized to leave room for levels that are larger than it: RT_TREE_ROOM
     // times.  A level that still does not fit halves the batch (below).
     const bool tree_levels = ds->has_ggx && args->mode == RT_MODE_FAST && !static_memory &&
-                             (args->flags & (RT_RENDER_TREE_DEPTH_FIRST | RT_RENDER_NO_PACKETS | RT_RENDER_UNFUSED_SHADOWS | RT_RENDER_UNFUSED_CAMERA)) == 0u &&
+                             (args->flags & (RT_RENDER_TREE_DEPTH_FIRST | RT_RENDER_NO_PACKETS | RT_RENDER_UNFUSED_SHADOWS | RT_RENDER_UNFUSED_CAMERA | RT_RENDER_CLOSEST_BLOCKERS)) == 0u &&
                              ds->n_point_lights <= 32;
     if (tree_levels) {
         const uint32_t room_slots = (uint32_t)std::min<uint64_t>(slots_per_batch, (uint64_t)std::max<uint32_t>(n_slots, 1) * RT_TREE_ROOM);
@@ -2056,7 +2059,10 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // fast mode: wave packets for camera and shadow rays, unless the caller asks for the per-lane kernels
     const bool use_packets = (args->flags & RT_RENDER_NO_PACKETS) == 0u;
     // shadow rays and light sums in one kernel: needs the packet path and a bit per point light
-    const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u;
+    // fast mode with shadow rays that run to the closest blocker, so that their ids compare with the reference's: the
+    // separate shadow kernel, which keeps a blocker per ray and light
+    const bool closest_blockers = !ref_order && use_packets && (args->flags & RT_RENDER_CLOSEST_BLOCKERS) != 0u;
+    const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u && !closest_blockers;
     // camera rays and the stage behind them in one kernel: needs the packet path
     const bool fuse_camera = !ref_order && use_packets && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
     // all mirror bounces (their rays and the stage behind them) in one kernel
@@ -2240,6 +2246,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
                     const dim3 sg(full_grid, ds->n_point_lights);
                     if (ref_order)
                         hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
+                    else if (use_packets && closest_blockers)
+                        hipLaunchKernelGGL((k_trace_packet<2, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, 0u);
                     else if (use_packets)
                         hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, 0u);
                     else

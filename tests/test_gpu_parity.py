@@ -579,6 +579,15 @@ def test_headline_workload_matches_oracle_at_full_size(rt, backend, scene_path):
     print("bunny 1000^2 parity, reference order (blocker ids):", im_r, idm_r)
     assert idm_r["shadow_rays_compared"] >= 12_000_000 and idm_r["shadow"] >= 0.9999
     assert abs(stats_r.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
+    # The same one-to-one comparison in FAST mode: RT_RENDER_CLOSEST_BLOCKERS lets its shadow rays run to the closest
+    # blocker too (packets on the mode's own trees: a closest hit does not depend on the tree), and the frame is the
+    # fast mode's frame bit for bit.
+    fb_c, ids_c, stats_c = dev.render(3, want_ids=True, flags=rt.RT_RENDER_CLOSEST_BLOCKERS)
+    im_c, idm_c = parity.assert_parity(fb_c.pixels, ids_c, ref_fb, ref_ids, occlusion_only=False, label="bunny 1000^2, fast mode, closest blockers")
+    print("bunny 1000^2 parity, fast mode with closest blockers (blocker ids):", im_c, idm_c, "frame %.3f ms" % stats_c.render_ms)
+    assert idm_c["shadow_rays_compared"] >= 12_000_000 and idm_c["shadow"] >= 0.9999
+    assert np.array_equal(fb_c.pixels, fb.pixels)
+    assert stats_c.total_rays() == stats.total_rays()
     dev.close()
 
 
