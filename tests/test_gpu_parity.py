@@ -747,6 +747,11 @@ def test_other_workloads_match_oracle_at_full_size(rt, backend, scene_path, name
     assert abs(stats.total_rays() - sum(counters["rays"])) <= 1e-4 * sum(counters["rays"])
     again, _, again_stats = dev.render(3)  # queue appends and compaction leave no trace of their order
     assert np.array_equal(again.pixels, fb.pixels) and again_stats.total_rays() == stats.total_rays()
+    # blocker ids, one to one (shadow rays behind mirror chains included): the fast mode with closest-hit shadow rays
+    fb_c, ids_c, stats_c = dev.render(3, want_ids=True, flags=rt.RT_RENDER_CLOSEST_BLOCKERS)
+    im_c, idm_c = parity.assert_parity(fb_c.pixels, ids_c, ref_fb, ref_ids, occlusion_only=False, label=name + " 1000^2, closest blockers")
+    print(name, "1000^2 parity, fast mode with closest blockers (blocker ids):", idm_c)
+    assert idm_c["shadow"] >= 0.9999 and np.array_equal(fb_c.pixels, fb.pixels) and stats_c.total_rays() == stats.total_rays()
     dev.close()
 
 
