@@ -194,6 +194,9 @@ int main(int argc, char **argv) {
     RtRayIds ids;
     std::memset(&ids, 0, sizeof(ids));
     if (!dump_ids.empty()) {
+        // ids that are to be compared with another renderer's: the fast mode's shadow rays then run to the closest
+        // blocker too (light/point.rs:35) instead of stopping at the first one they find; the picture is the same
+        if (mode == RT_MODE_FAST) ra.flags |= RT_RENDER_CLOSEST_BLOCKERS;
         id_store.assign(samples * (5 + 2 * npl), -1);
         int32_t *at = id_store.data();
         ids.primary_shape = at; at += samples;
