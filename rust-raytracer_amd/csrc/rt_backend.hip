@@ -1730,6 +1730,167 @@ bool rt::is_pinned_host(const void *p) {
 
 namespace {
 
+// What a frame's arguments come to: checked once (plan_frame), read by every step of rt::render_frame.
+struct FramePlan {
+    Window win{};                   // the rendered pixels: RtRenderArgs' window, else the whole frame
+    uint32_t W = 0, H = 0;          // win.w x win.h, which the tiles are laid over
+    uint32_t tw = 0, th = 0, tiles_x = 0, tiles_y = 0;
+    uint32_t n = 0, spp = 0;        // sqrt_rays_per_pixel and its square
+    uint64_t tile_samples = 0;
+    uint32_t parts = 1;             // the frame's split ...
+    uint32_t span = 1;              // ... how many of its parts this call renders (RtRenderArgs::part_span) ...
+    uint32_t pitch_tiles = 0;       // ... and, for more than one, the distance between their compact blocks in tiles
+    // dynamic LDS: per-lane kernels (stack rows + auxiliary rows per thread); packet kernels (stack rows and the
+    // world-space rays of a wave inside an instance, plus the fused shadow kernel's seven words per lane / the
+    // camera kernel's plane point / the bounce kernel's tally and kept ray)
+    size_t lds_bytes = 0, packet_lds = 0, camera_lds = 0, bounce_lds = 0;
+    // which kernels a batch goes through
+    bool ref_order = false;         // RT_MODE_REFERENCE_ORDER: the separate per-lane kernels throughout
+    bool use_packets = false;       // fast mode: wave packets for camera and shadow rays, unless the caller asks for the per-lane kernels
+    bool closest_blockers = false;  // fast mode with shadow rays that run to the closest blocker, so that their ids compare with
+                                    // the reference's: the separate shadow kernel, which keeps a blocker per ray and light
+    bool fused = false;             // shadow rays and light sums in one kernel: needs the packet path and a bit per point light
+    bool fuse_camera = false;       // camera rays and the stage behind them in one kernel: needs the packet path
+    bool fuse_bounce = false;       // all mirror bounces (their rays and the stage behind them) in one kernel
+    // The kernels that find the lit hits list them as they go, each chunk of samples in a stretch of its own, and the
+    // fused shadow kernel takes the stretches as they are: no scan and no scatter launch between them.  (Every other
+    // combination of kernels goes through the compact, ascending list.)
+    bool direct_lit = false;
+    // Ray trees level by level (see k_tree_count): fast mode with all its fused kernels.  The call waits for the device
+    // between levels (it reads how many rays the next level has), enqueue-only entry points too: a frame takes a
+    // quarter of the depth-first kernel's time, which is worth more to a stream of frames than a call that returns
+    // at once (RT_RENDER_TREE_DEPTH_FIRST is for callers who must not wait; the static work memory, whose users
+    // may be capturing a graph, always goes depth first).
+    bool tree_levels = false;
+    int max_bounce = 0;
+    // a wait per batch: to read the counters for the statistics, or to serve the progress callback
+    bool serve_progress = false, wait_batches = false;
+};
+
+int plan_frame(const RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, const float *fb_dev, bool with_stats,
+               bool blocking, bool static_memory, FramePlan &P) {
+    if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
+    if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
+    if (args->antialias_method < RT_AA_NORMAL || args->antialias_method > RT_AA_RANDOM)
+        return rt::set_error(RT_ERR_INVALID, "antialias_method must be RT_AA_NORMAL, RT_AA_JITTERED or RT_AA_RANDOM");
+    P.n = args->sqrt_rays_per_pixel;
+    if (P.n == 0 || P.n > 255) return rt::set_error(RT_ERR_INVALID, "sqrt_rays_per_pixel must be in 1..255");
+    if (args->mode != RT_MODE_FAST && args->mode != RT_MODE_REFERENCE_ORDER)
+        return rt::set_error(RT_ERR_INVALID, "unknown traversal mode");
+    P.parts = std::max<uint32_t>(args->part_count, 1);
+    if (int bad = check_partition(args)) return bad;
+    P.tw = args->tile_w ? args->tile_w : 32;
+    P.th = args->tile_h ? args->tile_h : 32;
+    if (int bad = resolve_window(args, ds->width, ds->height, P.win)) return bad;
+    P.W = P.win.w;
+    P.H = P.win.h;
+    P.tiles_x = (P.W + P.tw - 1) / P.tw;
+    P.tiles_y = (P.H + P.th - 1) / P.th;
+    P.spp = P.n * P.n;
+    P.tile_samples = (uint64_t)P.tw * P.th * P.spp;
+    if (P.tile_samples > (1ull << 30)) return rt::set_error(RT_ERR_INVALID, "tile too large");
+    if (ds->view.recursion_depth > 30) return rt::set_error(RT_ERR_INVALID, "recursion depth above 30");
+
+    P.ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
+    const RtSceneView &S = P.ref_order ? ds->view : ds->view_fast;
+    P.lds_bytes = (size_t)(std::max(S.stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
+    if (P.lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
+    const size_t packet_rows = (size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1);
+    P.packet_lds = (packet_rows + 7u * 64u) * sizeof(int32_t);
+    P.camera_lds = (packet_rows + 4u * 64u) * sizeof(int32_t);
+    P.bounce_lds = (packet_rows + (1u + RT_BOUNCE_KEEP) * 64u) * sizeof(int32_t);
+
+    if (static_memory && (P.parts > 1 || with_stats))
+        return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames (part_count <= 1) and no statistics");
+    // Several parts in one set of launches (RtRenderArgs::part_span): the tiles of all of them, in image order, each
+    // with the place it goes to -- part (part_index + j) % parts writes its compact block j * pitch tiles into the
+    // framebuffer.  One part: slot k of the list goes to place k.
+    P.span = P.parts > 1 ? std::max<uint32_t>(args->part_span, 1) : 1;
+    if (P.span > P.parts) return rt::set_error(RT_ERR_INVALID, "part_span exceeds part_count");
+    if (P.span > 1 && static_memory) return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames");
+    if (P.span > 1) {
+        const std::vector<uint32_t> counts = part_tile_counts(P.tiles_x, P.tiles_y, P.parts, args->part0_weight);
+        const uint32_t most = *std::max_element(counts.begin(), counts.end());
+        const uint64_t tile_floats = (uint64_t)P.tw * P.th * 3;
+        if (args->part_span_pitch_floats % tile_floats != 0)
+            return rt::set_error(RT_ERR_INVALID, "part_span_pitch_floats must be a whole number of tiles");
+        P.pitch_tiles = args->part_span_pitch_floats ? (uint32_t)(args->part_span_pitch_floats / tile_floats) : most;
+        if (P.pitch_tiles < most) return rt::set_error(RT_ERR_INVALID, "part_span_pitch_floats smaller than a part's block of tiles");
+    }
+
+    const uint32_t flags = args->flags;
+    P.use_packets = (flags & RT_RENDER_NO_PACKETS) == 0u;
+    P.closest_blockers = !P.ref_order && P.use_packets && (flags & RT_RENDER_CLOSEST_BLOCKERS) != 0u;
+    P.fused = !P.ref_order && P.use_packets && ds->n_point_lights <= 32 && (flags & RT_RENDER_UNFUSED_SHADOWS) == 0u && !P.closest_blockers;
+    P.fuse_camera = !P.ref_order && P.use_packets && (flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
+    P.fuse_bounce = !P.ref_order && (flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
+    P.direct_lit = P.fused && P.fuse_camera && P.fuse_bounce;
+    P.tree_levels = ds->has_ggx && !P.ref_order && !static_memory && ds->n_point_lights <= 32 &&
+                    (flags & (RT_RENDER_TREE_DEPTH_FIRST | RT_RENDER_NO_PACKETS | RT_RENDER_UNFUSED_SHADOWS | RT_RENDER_UNFUSED_CAMERA |
+                              RT_RENDER_CLOSEST_BLOCKERS)) == 0u;
+    P.max_bounce = ds->has_mirror ? S.recursion_depth : 0;
+    P.serve_progress = (blocking || with_stats) && args->progress != nullptr;
+    P.wait_batches = with_stats || P.serve_progress;
+    return RT_OK;
+}
+
+// The backend's list of the tiles this call renders (and, for several parts, of the places they go to), kept from
+// call to call for as long as the partition stays the same.
+int refresh_tile_list(RtBackend *be, const RtRenderArgs *args, const FramePlan &P) {
+    const uint32_t key[8] = {P.W, P.H, P.tw, P.th, args->part_index, P.parts | (args->part0_weight << 24), P.span, P.pitch_tiles};
+    if (std::memcmp(key, be->tile_key, sizeof(key)) == 0 && be->tile_list) return RT_OK;
+    std::vector<int32_t> &tiles = be->tile_list_host, &places = be->tile_place_host;
+    places.clear();
+    if (P.span <= 1) {
+        owned_tiles(P.tiles_x, P.tiles_y, args->part_index, P.parts, args->part0_weight, tiles);
+    } else {
+        std::vector<std::pair<int32_t, int32_t>> all;  // (tile, place)
+        std::vector<int32_t> one;
+        for (uint32_t j = 0; j < P.span; ++j) {
+            owned_tiles(P.tiles_x, P.tiles_y, (args->part_index + j) % P.parts, P.parts, args->part0_weight, one);
+            for (size_t k = 0; k < one.size(); ++k) all.emplace_back(one[k], (int32_t)(j * P.pitch_tiles + k));
+        }
+        std::sort(all.begin(), all.end());  // image order: neighbouring tiles are worked on together
+        tiles.clear();
+        for (const auto &e : all) {
+            tiles.push_back(e.first);
+            places.push_back(e.second);
+        }
+    }
+    if (be->tile_list) (void)hipFree(be->tile_list);
+    be->tile_list = nullptr;
+    // the tiles, and behind them their places if they have any
+    const size_t count = tiles.size();
+    RT_HIP(hipMalloc((void **)&be->tile_list, std::max<size_t>(2 * count, 1) * sizeof(int32_t)));
+    if (count) RT_HIP(hipMemcpy(be->tile_list, tiles.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!places.empty()) RT_HIP(hipMemcpy(be->tile_list + count, places.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::memcpy(be->tile_key, key, sizeof(key));
+    return RT_OK;
+}
+
+// As many tiles per batch as the device's static array holds (at most `most`), by bisection: the bytes grow with the
+// tiles, but one tile's bytes are no guide to it -- every array is padded to 256 bytes and the counter sets have a
+// fixed part, some 13 KB that a batch pays once, not once per tile.
+int static_batch_slots(const RtDeviceScene *ds, const FramePlan &P, uint64_t most, uint32_t &fit) {
+    auto fits = [&](uint64_t tiles) { return buffer_bytes((uint32_t)(tiles * P.tile_samples), ds->n_point_lights) <= (size_t)RT_STATIC_SCRATCH_BYTES; };
+    fit = 0;
+    if (fits(1)) {
+        uint64_t lo = 1, hi = most;  // lo fits
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi + 1) / 2;
+            if (fits(mid)) lo = mid;
+            else hi = mid - 1;
+        }
+        fit = (uint32_t)lo;
+    }
+    if (fit == 0)
+        return rt::set_error(RT_ERR_INVALID, "one tile of " + std::to_string(P.tile_samples) + " samples with " + std::to_string(ds->n_point_lights) +
+                                                 " point lights needs " + std::to_string(buffer_bytes((uint32_t)P.tile_samples, ds->n_point_lights)) +
+                                                 " bytes of work memory; the static array holds " + std::to_string((size_t)RT_STATIC_SCRATCH_BYTES) +
+                                                 ": use smaller tiles or fewer rays per pixel");
+    return RT_OK;
+}
+
 // One batch of ray trees, level by level (see k_tree_count): level 0 = the batch's camera rays, level L + 1 = what the
 // GGX hits of level L spawn, each level through the fast mode's fused kernels with `Q`'s arrays as its work memory;
 // then the children's colours into their parents, deepest level first, which leaves the samples' colours in Q.color.
@@ -1739,9 +1900,10 @@ struct TreeBatch {
     bool too_large = false;
     uint64_t secondary = 0, lit = 0;
 };
-int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, hipStream_t stream, bool stats, Timing &tm,
-                      const RtSceneView &S, RtBuffers Q, const RtBatch &B, const RtIdOut &io, uint32_t n_samples, size_t camera_lds,
-                      size_t packet_lds, size_t bounce_lds, TreeBatch &out) {
+int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, const FramePlan &P, hipStream_t stream,
+                      bool stats, Timing &tm, const RtSceneView &S, RtBuffers Q, const RtBatch &B, const RtIdOut &io, uint32_t n_samples,
+                      TreeBatch &out) {
+    const size_t camera_lds = P.camera_lds, packet_lds = P.packet_lds, bounce_lds = P.bounce_lds;
     int rc = RT_OK;
     // ---- level 0: the camera rays; level L + 1: what the GGX hits of level L spawn (see k_tree_count)
     RtBackend::TreeLevels &tl = be->tree;
@@ -1863,35 +2025,208 @@ int tree_levels_batch(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs
     return RT_OK;
 }
 
+
+// What a batch's kernels are told about it: the tiles `slot0 .. slot0 + slots - 1` of the call's list.
+RtBatch describe_batch(const RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, const FramePlan &P, bool static_memory,
+                       uint32_t slot0, uint32_t slots) {
+    RtBatch B{};
+    // (a render that owns every tile needs no list: slot k is tile k, and every wave is spared a fetch that its
+    // first arithmetic would have had to wait for)
+    B.tile_list = static_memory || P.parts <= 1 ? nullptr : be->tile_list;
+    B.tile_place = !static_memory && !be->tile_place_host.empty() ? be->tile_list + be->tile_list_host.size() : nullptr;
+    B.slot0 = slot0;
+    B.n_pixels = slots * P.tw * P.th;
+    B.tile_w = P.tw; B.tile_h = P.th; B.tiles_x = P.tiles_x;
+    B.width = ds->width; B.height = ds->height;
+    B.win_x0 = P.win.x0; B.win_y0 = P.win.y0; B.win_w = P.win.w; B.win_h = P.win.h;
+    B.n = P.n;
+    B.compact_fb = P.parts > 1 ? 1u : 0u;
+    B.fused_shadows = P.fused ? 1u : 0u;
+    B.direct_lit = P.direct_lit ? 1u : 0u;
+    B.chunked_queue = P.fuse_camera && P.fuse_bounce ? 1u : 0u;  // k_camera_shade_packet, then k_bounces_packet
+    B.light_sums_f32 = P.ref_order ? 0u : 1u;
+    B.aa_method = args->antialias_method;
+    B.seed = args->seed;
+    if ((args->flags & RT_RENDER_ROW_MAJOR_PIXELS) == 0u) rt_pixel_block(P.tw, P.th, P.spp, B.blk_w_log2, B.blk_h_log2);
+    rt_batch_finish(B);
+    return B;
+}
+
+// Counters and per-chunk lit counts start at zero.  A backend's batches take turns with two sets of them: where the
+// batch's first kernel is a camera-ray packet kernel (`clear_in_kernel`), that kernel zeroes the set the previous
+// batch used (for the next one), so that no memset stands in front of a frame; any other batch clears its own set with
+// a memset.  (The static work array is shared by all backends of a device, so nothing is known about its sets from
+// one call to the next: always a memset.)  Points Q's counter fields at the batch's set; `n_clear` = the words of the
+// other set that the batch's first kernel is to zero.
+int take_counter_set(RtBackend *be, RtBuffers &Q, uint32_t lit_grid, bool clear_in_kernel, bool static_memory, hipStream_t stream,
+                     uint32_t &n_clear) {
+    const uint32_t n_counters = (uint32_t)RT_CNT_SIZE + 2u * lit_grid;  // counters, lit hits per chunk, mirror rays per chunk
+    uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
+                               Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
+    const uint32_t set_words = (uint32_t)(sets[1] - sets[0]);
+    uint32_t dirty_static[2] = {~0u, ~0u};
+    uint32_t *dirty = static_memory ? dirty_static : be->counter_dirty;  // per set: how many leading words may be non-zero
+    // a clean set if there is one and this batch keeps the turns going, else a dirty one (and the memset)
+    int use = 0;
+    if (clear_in_kernel) use = dirty[0] == 0u ? 0 : dirty[1] == 0u ? 1 : 0;
+    else use = dirty[0] == 0u && dirty[1] != 0u ? 1 : 0;
+    if (dirty[use] != 0u) RT_HIP(hipMemsetAsync(sets[use], 0, (size_t)n_counters * sizeof(uint32_t), stream));
+    dirty[use] = std::max(dirty[use], n_counters);
+    n_clear = 0;
+    if (clear_in_kernel) {
+        n_clear = std::min(dirty[use ^ 1], set_words);
+        dirty[use ^ 1] = 0u;
+    }
+    Q.counters = sets[use];
+    Q.block_counts = Q.counters + RT_CNT_SIZE;
+    Q.mirror_counts = Q.block_counts + lit_grid;
+    Q.counters_next = sets[use ^ 1];
+    return RT_OK;
+}
+
+// The grids of a batch of `n_samples` samples.
+struct BatchGrids {
+    uint32_t full;       // a thread per sample (worst case for the per-lane kernels; blocks without work return at once)
+    uint32_t packets;    // a wave per 64 samples: one ray per lane (two per lane -- the packet kernels' R -- halve the steps per ray but were
+                         // slower in every measurement, bunny camera rays 0.36 -> 0.49 ms, shadow rays 0.88 -> 1.13: twice the registers, a larger union of nodes)
+    uint32_t lit;        // a block per chunk of the lit list
+    uint32_t xcd_chunk;  // chunk of the XCD remap in 256-sample blocks, a power of two (the kernels shift and mask)
+};
+BatchGrids batch_grids(const RtRenderArgs *args, uint32_t n_samples) {
+    BatchGrids g;
+    g.full = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
+    g.packets = (n_samples + RT_PACKET_BLOCK - 1) / RT_PACKET_BLOCK;
+    g.lit = (n_samples + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
+    // 128 (a few tiles) for a whole frame, smaller for a small launch so that every XCD still gets >= 32 chunks --
+    // chunks differ in cost, and with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
+    g.xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, g.full / 256u));
+    while ((g.xcd_chunk & (g.xcd_chunk - 1u)) != 0u) g.xcd_chunk &= g.xcd_chunk - 1u;
+    return g;
+}
+
+// A batch without ray trees through its stages: camera rays and the stage behind their hits, mirror bounces, the
+// lit list, shadow rays and light sums -- fused or kernel by kernel, as the plan says.  Leaves the samples'
+// colours in Q.color.
+int launch_stages(const RtDeviceScene *ds, const FramePlan &P, hipStream_t stream, bool stats, Timing &tm, const RtSceneView &S,
+                  const RtBuffers &Q, const RtBatch &B, const RtIdOut &io, uint32_t n_samples, const BatchGrids &G, uint32_t n_clear) {
+    for (int bounce = 0; bounce <= P.max_bounce; ++bounce) {
+        // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
+        // the device, so a fixed grid strides over it (and costs little when it is empty).
+        const uint32_t g = bounce == 0 ? G.full : std::min<uint32_t>(G.full, RT_MAX_GRID);
+        if (bounce > 0 && P.fuse_bounce) {  // one launch follows the rays of bounce 1 through all later bounces
+            if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+            if (P.use_packets) {
+                // With statistics: one resident set of waves striding over the packets, which hand their ray
+                // counts to the batch's counters once each.  Without: a wave per packet, dealt by the hardware
+                // as waves finish (mirror chains differ in length; a fixed deal waits for its unluckiest wave).
+                const uint32_t gp = stats ? std::min<uint32_t>(G.packets, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : G.packets;
+                hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), P.bounce_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u, TreeSpawn{});
+            } else {
+                const uint32_t gb = std::min<uint32_t>(G.full, RT_BOUNCE_GRID);
+                hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, B, io, G.xcd_chunk);
+            }
+            tm.end();
+            break;
+        }
+        if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        if (P.ref_order)
+            hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, B, bounce, n_samples, G.xcd_chunk);
+        else if (bounce == 0 && P.fuse_camera)
+            hipLaunchKernelGGL(k_camera_shade_packet, dim3(G.packets), dim3(RT_PACKET_BLOCK), P.camera_lds, stream, S, Q, B, io, n_samples, G.xcd_chunk, n_clear);
+        else if (bounce == 0 && P.use_packets)
+            hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(G.packets), dim3(RT_PACKET_BLOCK), P.packet_lds, stream, S, Q, B, n_samples, G.xcd_chunk, n_clear);
+        else
+            hipLaunchKernelGGL((k_trace_fast<0>), dim3(G.full), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, B, bounce, n_samples, G.xcd_chunk);
+        tm.end();
+        if (bounce == 0 && P.fuse_camera) continue;  // the camera-ray kernel has done the stage behind it too
+        if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        if (bounce == 0)
+            hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, 0, n_samples);
+        else
+            hipLaunchKernelGGL((k_shade<false>), dim3(G.full), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
+        tm.end();
+    }
+    if (!ds->has_lit) return RT_OK;
+    if (P.direct_lit) {
+        if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, Q, G.lit);
+    } else {
+        if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        if (G.lit <= RT_LIT_OWN_OFFSET_MAX) {
+            hipLaunchKernelGGL((k_lit_scatter<true>), dim3(G.lit), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+        } else {
+            hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, G.lit);
+            hipLaunchKernelGGL((k_lit_scatter<false>), dim3(G.lit), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
+        }
+        tm.end();
+    }
+    // the number of lit hits is only known on the device: the grids are sized for the worst case, surplus blocks
+    // return at once
+    if (P.fused) {
+        if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        hipLaunchKernelGGL(k_shadow_shade_packet, dim3(G.packets), dim3(RT_PACKET_BLOCK), P.packet_lds, stream, S, Q, B, io, G.xcd_chunk);
+        tm.end();
+        return RT_OK;
+    }
+    if (!S.disable_shadows && ds->n_point_lights > 0) {
+        if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+        if (P.ref_order)
+            hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(G.full, ds->n_point_lights), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, G.xcd_chunk);
+        else if (P.closest_blockers)
+            hipLaunchKernelGGL((k_trace_packet<2, 1>), dim3(G.packets, ds->n_point_lights), dim3(RT_PACKET_BLOCK), P.packet_lds, stream, S, Q, B, n_samples, G.xcd_chunk, 0u);
+        else if (P.use_packets)
+            hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(G.packets, ds->n_point_lights), dim3(RT_PACKET_BLOCK), P.packet_lds, stream, S, Q, B, n_samples, G.xcd_chunk, 0u);
+        else
+            hipLaunchKernelGGL((k_trace_fast<1>), dim3(G.full, ds->n_point_lights), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, B, 0, n_samples, G.xcd_chunk);
+        tm.end();
+    }
+    if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
+    hipLaunchKernelGGL(k_accumulate, dim3(G.full), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
+    tm.end();
+    return RT_OK;
+}
+
+// Pixels of the call's tiles `from .. to - 1` that lie inside the rendered rectangle.
+uint64_t pixels_inside(const RtBackend *be, const FramePlan &P, uint32_t from, uint32_t to) {
+    uint64_t px = 0;
+    for (uint32_t k = from; k < to; ++k) {
+        const uint32_t tile = (uint32_t)be->tile_list_host[k];
+        const uint32_t x0 = (tile % P.tiles_x) * P.tw, y0 = (tile / P.tiles_x) * P.th;
+        px += (uint64_t)std::min(P.tw, P.W - x0) * std::min(P.th, P.H - y0);
+    }
+    return px;
+}
+
+// The ray counts of a frame from what its batches left: `host_counters` holds RT_CNT_SIZE words per batch that
+// went through the stages or the depth-first tree kernel, `tree_secondary` / `tree_lit` the sums over the batches
+// that went level by level.
+void add_up_ray_counts(RtStats *stats, const RtBackend *be, const RtDeviceScene *ds, const FramePlan &P, const RtSceneView &S,
+                       const std::vector<uint32_t> &host_counters, uint64_t tree_secondary, uint64_t tree_lit) {
+    // camera rays = samples of the owned pixels that lie inside the image
+    stats->primary_rays += pixels_inside(be, P, 0, (uint32_t)be->tile_list_host.size()) * P.spp;
+    stats->secondary_rays += tree_secondary;
+    stats->shaded_hits += tree_lit;
+    if (!S.disable_shadows) stats->shadow_rays += tree_lit * ds->n_point_lights;
+    for (size_t at = 0; at < host_counters.size(); at += RT_CNT_SIZE) {
+        const uint32_t *c = host_counters.data() + at;
+        if (ds->has_ggx) {
+            auto wide = [&](int word) { return (uint64_t)c[word] | ((uint64_t)c[word + 1] << 32); };
+            stats->secondary_rays += wide(RT_CNT_TREE_SECONDARY);
+            stats->shadow_rays += wide(RT_CNT_TREE_SHADOW);
+            stats->shaded_hits += wide(RT_CNT_TREE_SHADED);
+        } else {
+            for (int b = 1; b <= P.max_bounce && b < 32; ++b) stats->secondary_rays += c[RT_CNT_RAYS0 + b];
+            stats->shaded_hits += c[RT_CNT_LIT];
+            if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_LIT] * ds->n_point_lights;
+        }
+    }
+}
+
 }  // namespace
 
 int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
                      hipStream_t stream, RtStats *stats, bool blocking, bool static_memory) {
-    if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
-    if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
-    if (args->antialias_method < RT_AA_NORMAL || args->antialias_method > RT_AA_RANDOM)
-        return rt::set_error(RT_ERR_INVALID, "antialias_method must be RT_AA_NORMAL, RT_AA_JITTERED or RT_AA_RANDOM");
-    const uint32_t n = args->sqrt_rays_per_pixel;
-    if (n == 0 || n > 255) return rt::set_error(RT_ERR_INVALID, "sqrt_rays_per_pixel must be in 1..255");
-    if (args->mode != RT_MODE_FAST && args->mode != RT_MODE_REFERENCE_ORDER)
-        return rt::set_error(RT_ERR_INVALID, "unknown traversal mode");
-    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    if (int bad = check_partition(args)) return bad;
-    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    // W x H: the rendered pixels (the window, else the frame), which the tiles are laid over
-    Window win;
-    if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
-    const uint32_t W = win.w, H = win.h;
-    const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-    const uint32_t spp = n * n;
-    const uint64_t tile_samples = (uint64_t)tw * th * spp;
-    if (tile_samples > (1ull << 30)) return rt::set_error(RT_ERR_INVALID, "tile too large");
-    if (ds->view.recursion_depth > 30) return rt::set_error(RT_ERR_INVALID, "recursion depth above 30");
-
-    const int mode_stack_depth = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view.stack_depth : ds->view_fast.stack_depth;
-    const size_t lds_bytes = (size_t)(std::max(mode_stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
-    if (lds_bytes > 64 * 1024) return rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack");
-
+    FramePlan P;
+    if (int bad = plan_frame(be, ds, args, fb_dev, stats != nullptr, blocking, static_memory, P)) return bad;
     RT_HIP(hipSetDevice(be->device));
     if (!stream) stream = be->stream;
     struct InCall {  // rt_render_device_static: one call per device at a time (StaticSlot)
@@ -1910,127 +2245,52 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         RT_HIP(hipStreamWaitEvent(stream, slot.done, 0));
     }
 
-    // ---- tile list (cached per partition); a whole frame in static memory needs none: slot k is tile k
-    if (static_memory && (parts > 1 || stats != nullptr))
-        return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames (part_count <= 1) and no statistics");
-    // Several parts in one set of launches (RtRenderArgs::part_span): the tiles of all of them, in image order, each
-    // with the place it goes to -- part (part_index + j) % parts writes its compact block j * pitch tiles into the
-    // framebuffer.  One part: slot k of the list goes to place k.
-    const uint32_t span = parts > 1 ? std::max<uint32_t>(args->part_span, 1) : 1;
-    if (span > parts) return rt::set_error(RT_ERR_INVALID, "part_span exceeds part_count");
-    if (span > 1 && static_memory) return rt::set_error(RT_ERR_INVALID, "a render in static memory takes whole frames");
-    uint32_t pitch_tiles = 0;
-    if (span > 1) {
-        const std::vector<uint32_t> counts = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight);
-        const uint32_t most = *std::max_element(counts.begin(), counts.end());
-        const uint64_t tile_floats = (uint64_t)tw * th * 3;
-        if (args->part_span_pitch_floats % tile_floats != 0)
-            return rt::set_error(RT_ERR_INVALID, "part_span_pitch_floats must be a whole number of tiles");
-        pitch_tiles = args->part_span_pitch_floats ? (uint32_t)(args->part_span_pitch_floats / tile_floats) : most;
-        if (pitch_tiles < most) return rt::set_error(RT_ERR_INVALID, "part_span_pitch_floats smaller than a part's block of tiles");
-    }
-    const uint32_t key[8] = {W, H, tw, th, args->part_index, parts | (args->part0_weight << 24), span, pitch_tiles};
-    if (!static_memory && (std::memcmp(key, be->tile_key, sizeof(key)) != 0 || !be->tile_list)) {
-        std::vector<int32_t> &tiles = be->tile_list_host, &places = be->tile_place_host;
-        places.clear();
-        if (span <= 1) {
-            owned_tiles(tiles_x, tiles_y, args->part_index, parts, args->part0_weight, tiles);
-        } else {
-            std::vector<std::pair<int32_t, int32_t>> all;  // (tile, place)
-            std::vector<int32_t> one;
-            for (uint32_t j = 0; j < span; ++j) {
-                owned_tiles(tiles_x, tiles_y, (args->part_index + j) % parts, parts, args->part0_weight, one);
-                for (size_t k = 0; k < one.size(); ++k) all.emplace_back(one[k], (int32_t)(j * pitch_tiles + k));
-            }
-            std::sort(all.begin(), all.end());  // image order: neighbouring tiles are worked on together
-            tiles.clear();
-            for (const auto &e : all) {
-                tiles.push_back(e.first);
-                places.push_back(e.second);
-            }
-        }
-        if (be->tile_list) (void)hipFree(be->tile_list);
-        be->tile_list = nullptr;
-        // the tiles, and behind them their places if they have any
-        const size_t count = tiles.size();
-        RT_HIP(hipMalloc((void **)&be->tile_list, std::max<size_t>(2 * count, 1) * sizeof(int32_t)));
-        if (count) RT_HIP(hipMemcpy(be->tile_list, tiles.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
-        if (!places.empty()) RT_HIP(hipMemcpy(be->tile_list + count, places.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
-        std::memcpy(be->tile_key, key, sizeof(key));
-    }
-    const uint32_t n_slots = static_memory ? tiles_x * tiles_y : (uint32_t)be->tile_list_host.size();
+    // ---- the tiles of this call; a whole frame in static memory needs no list: slot k is tile k
+    int rc = RT_OK;
+    if (!static_memory && (rc = refresh_tile_list(be, args, P))) return rc;
+    const uint32_t n_slots = static_memory ? P.tiles_x * P.tiles_y : (uint32_t)be->tile_list_host.size();
 
-    // ---- batch size
+    // ---- tiles per batch, and work memory for a batch
     // (32 Mi samples, 8.5 GB of work buffers with two point lights: the 3840 x 2160 frame at 64 rays per pixel takes
     // 36.3 ms in batches of 16 Mi, 35.4 of 32 Mi, 34.9 of 64 Mi -- fewer, larger launches, fewer kernel tails)
     const uint64_t max_batch = args->batch_samples ? args->batch_samples : (32ull << 20);
-    uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / tile_samples);
-    RtBuffers carved;
-    if (static_memory) {
-        // as many tiles as the device's static array holds; the arrays are laid out in it afresh on every call
-        // The largest number of tiles whose arrays fit, by bisection (the bytes grow with the tiles).  One tile's
-        // bytes are no guide to it: every array is padded to 256 bytes and the counter sets have a fixed part,
-        // some 13 KB that a batch pays once, not once per tile.
-        const size_t per_tile = buffer_bytes((uint32_t)tile_samples, ds->n_point_lights);
-        auto fits = [&](uint64_t tiles) { return buffer_bytes((uint32_t)(tiles * tile_samples), ds->n_point_lights) <= (size_t)RT_STATIC_SCRATCH_BYTES; };
-        uint32_t fit = 0;
-        if (fits(1)) {
-            uint64_t lo = 1, hi = std::min<uint64_t>(slots_per_batch, std::max<uint32_t>(n_slots, 1));  // lo fits
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi + 1) / 2;
-                if (fits(mid)) lo = mid;
-                else hi = mid - 1;
-            }
-            fit = (uint32_t)lo;
-        }
-        if (fit == 0)
-            return rt::set_error(RT_ERR_INVALID, "one tile of " + std::to_string(tile_samples) + " samples with " +
-                                                     std::to_string(ds->n_point_lights) + " point lights needs " + std::to_string(per_tile) +
-                                                     " bytes of work memory; the static array holds " +
-                                                     std::to_string((size_t)RT_STATIC_SCRATCH_BYTES) + ": use smaller tiles or fewer rays per pixel");
-        slots_per_batch = fit;
-    }
+    uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / P.tile_samples);
+    if (static_memory && (rc = static_batch_slots(ds, P, std::min<uint64_t>(slots_per_batch, std::max<uint32_t>(n_slots, 1)), slots_per_batch)))
+        return rc;
     uint32_t batch_slots = std::min(slots_per_batch, std::max<uint32_t>(n_slots, 1));
-    uint32_t capacity = (uint32_t)(batch_slots * tile_samples);
-    // Ray trees level by level (see k_tree_count): fast mode with all its fused kernels.  The call waits for the device
-    // between levels (it reads how many rays the next level has), enqueue-only entry points too: a frame takes a
-    // quarter of the depth-first kernel's time, which is worth more to a stream of frames than a call that returns
-    // at once (RT_RENDER_TREE_DEPTH_FIRST is for callers who must not wait; the static work memory, whose users
-    // may be capturing a graph, always goes depth first).  A level's rays lie in the batch buffers like a batch's
-    // samples, so a batch of camera rays is sized to leave room for levels that are larger than it: RT_TREE_ROOM
-    // times.  A level that still does not fit halves the batch (below).
-    const bool tree_levels = ds->has_ggx && args->mode == RT_MODE_FAST && !static_memory &&
-                             (args->flags & (RT_RENDER_TREE_DEPTH_FIRST | RT_RENDER_NO_PACKETS | RT_RENDER_UNFUSED_SHADOWS | RT_RENDER_UNFUSED_CAMERA | RT_RENDER_CLOSEST_BLOCKERS)) == 0u &&
-                             ds->n_point_lights <= 32;
-    if (tree_levels) {
+    uint32_t capacity = (uint32_t)(batch_slots * P.tile_samples);
+    if (P.tree_levels) {
+        // A level's rays lie in the batch buffers like a batch's samples, so a batch of camera rays is sized to
+        // leave room for levels that are larger than it: RT_TREE_ROOM times.  A level that still does not fit
+        // halves the batch (below).
         const uint32_t room_slots = (uint32_t)std::min<uint64_t>(slots_per_batch, (uint64_t)std::max<uint32_t>(n_slots, 1) * RT_TREE_ROOM);
         batch_slots = std::min(std::max<uint32_t>(n_slots, 1), std::max<uint32_t>(1, room_slots / RT_TREE_ROOM));
-        capacity = (uint32_t)(std::max(room_slots, batch_slots) * tile_samples);
+        capacity = (uint32_t)(std::max(room_slots, batch_slots) * P.tile_samples);
     }
-    int rc = RT_OK;
-    if (static_memory) {
+    RtBuffers Q;
+    if (static_memory) {  // the arrays are laid out in the device's static array afresh on every call
         size_t used = 0;
         unsigned char *base = be->scratch;
-        assign_buffers(carved, capacity, ds->n_point_lights, [&](size_t bytes) -> void * {
+        assign_buffers(Q, capacity, ds->n_point_lights, [&](size_t bytes) -> void * {
             void *p = base + used;
             used += (bytes + 255u) & ~(size_t)255u;
             return p;
         });
-        carved.overflow = be->sticky;
-    } else if ((rc = ensure_buffers(be, capacity, ds->n_point_lights))) {
-        return rc;
+        Q.overflow = be->sticky;
+    } else {
+        if ((rc = ensure_buffers(be, capacity, ds->n_point_lights))) return rc;
+        if (P.tree_levels && (rc = ensure_tree_buffers(be, be->buf_capacity, 2))) return rc;
+        Q = be->buf;
     }
-    if (tree_levels && (rc = ensure_tree_buffers(be, be->buf_capacity, 2))) return rc;
-    RtBuffers Q = static_memory ? carved : be->buf;
-    Q.lit_f32 = args->mode == RT_MODE_REFERENCE_ORDER ? 0u : 1u;
-    const RtSceneView &S = args->mode == RT_MODE_REFERENCE_ORDER ? ds->view : ds->view_fast;
+    Q.lit_f32 = P.ref_order ? 0u : 1u;
+    const RtSceneView &S = P.ref_order ? ds->view : ds->view_fast;
 
     RtIdOut io{};
     if (ids) {
         io.primary_shape = ids->primary_shape; io.primary_tri = ids->primary_tri;
         io.final_shape = ids->final_shape; io.final_tri = ids->final_tri; io.bounces = ids->bounces;
         io.shadow_shape = ids->shadow_shape; io.shadow_tri = ids->shadow_tri;
-        const size_t total = (size_t)W * H * spp * ds->n_point_lights;
+        const size_t total = (size_t)P.W * P.H * P.spp * ds->n_point_lights;
         if (io.shadow_shape && total) hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(total)), dim3(RT_BLOCK), 0, stream, io.shadow_shape, total, -2);
         if (io.shadow_tri && total) hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(total)), dim3(RT_BLOCK), 0, stream, io.shadow_tri, total, -2);
     }
@@ -2046,46 +2306,16 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (b) (void)hipEventDestroy(b);
         }
     } frame_ev;
-    hipEvent_t &ev0 = frame_ev.a, &ev1 = frame_ev.b;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        RT_HIP(hipEventCreate(&ev0));
-        RT_HIP(hipEventCreate(&ev1));
-        RT_HIP(hipEventRecord(ev0, stream));
+        RT_HIP(hipEventCreate(&frame_ev.a));
+        RT_HIP(hipEventCreate(&frame_ev.b));
+        RT_HIP(hipEventRecord(frame_ev.a, stream));
     }
-    const bool ref_order = args->mode == RT_MODE_REFERENCE_ORDER;
-    const int max_bounce = ds->has_mirror ? S.recursion_depth : 0;
-    std::vector<uint32_t> host_counters;
-    // fast mode: wave packets for camera and shadow rays, unless the caller asks for the per-lane kernels
-    const bool use_packets = (args->flags & RT_RENDER_NO_PACKETS) == 0u;
-    // shadow rays and light sums in one kernel: needs the packet path and a bit per point light
-    // fast mode with shadow rays that run to the closest blocker, so that their ids compare with the reference's: the
-    // separate shadow kernel, which keeps a blocker per ray and light
-    const bool closest_blockers = !ref_order && use_packets && (args->flags & RT_RENDER_CLOSEST_BLOCKERS) != 0u;
-    const bool fused = !ref_order && use_packets && ds->n_point_lights <= 32 && (args->flags & RT_RENDER_UNFUSED_SHADOWS) == 0u && !closest_blockers;
-    // camera rays and the stage behind them in one kernel: needs the packet path
-    const bool fuse_camera = !ref_order && use_packets && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
-    // all mirror bounces (their rays and the stage behind them) in one kernel
-    const bool fuse_bounce = !ref_order && (args->flags & RT_RENDER_UNFUSED_CAMERA) == 0u;
-    // The kernels that find the lit hits list them as they go, each chunk of samples in a stretch of its own, and the
-    // fused shadow kernel takes the stretches as they are: no scan and no scatter launch between them.  (Every other
-    // combination of kernels goes through the compact, ascending list.)
-    const bool direct_lit = fused && fuse_camera && fuse_bounce;
-    // One ray per lane in the packet kernels.  Two per lane (the template's R) halve the steps per
-    // ray but were slower in every measurement (bunny frame: camera rays 0.36 -> 0.49 ms, shadow rays
-    // 0.88 -> 1.13 ms): the wave needs twice the registers, and its union of nodes grows.
-    constexpr int packet_rays = 1;
-    // stack rows, the world-space rays of a wave inside an instance, and (fused kernel) a word per lane
-    const size_t packet_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 7u * 64u) * sizeof(int32_t);  // + the fused kernel's seven words per lane
-    const size_t camera_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + 4u * 64u) * sizeof(int32_t);  // + the plane point
-    const size_t bounce_lds = ((size_t)rt_packet_lds_dwords(std::max(S.stack_depth, 1) + 1) + (1u + RT_BOUNCE_KEEP) * 64u) * sizeof(int32_t);  // + tally, kept ray
-    // a wait per batch: to read the counters for the statistics, or to serve the progress callback
-    const bool serve_progress = (blocking || stats != nullptr) && args->progress != nullptr;
-    const bool wait_batches = stats != nullptr || serve_progress;
 
-    // Which of the backend's two counter sets is clean is noted below BEFORE the kernels that do the clearing are
-    // enqueued; any way out of this function other than the last line leaves that note untrue, so it is taken
-    // back: both sets count as dirty and the next frame clears what it uses with a memset.
+    // Which of the backend's two counter sets is clean is noted (take_counter_set) BEFORE the kernels that do the
+    // clearing are enqueued; any way out of this function other than the last line leaves that note untrue, so it is
+    // taken back: both sets count as dirty and the next frame clears what it uses with a memset.
     struct DirtyGuard {
         RtBackend *be;
         bool armed;
@@ -2093,73 +2323,25 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             if (armed) be->counter_dirty[0] = be->counter_dirty[1] = ~0u;
         }
     } dirty_guard{be, !static_memory};
+    std::vector<uint32_t> host_counters;  // with statistics: RT_CNT_SIZE words per batch
     // ray trees level by level: tiles per batch (halved when a level outgrows the buffers), what the levels' own
     // counters came to, and whether the batch at hand has fallen back to the depth-first kernel
     uint32_t tree_slots = batch_slots;
     uint64_t tree_secondary = 0, tree_lit = 0;
     bool tree_depth_first = false;
     for (uint32_t slot0 = 0, step = 0; slot0 < n_slots; slot0 += step) {
-        const uint32_t slots = std::min(tree_levels ? tree_slots : batch_slots, n_slots - slot0);
+        const uint32_t slots = std::min(P.tree_levels ? tree_slots : batch_slots, n_slots - slot0);
         step = slots;
-        RtBatch B{};
-        // (a render that owns every tile needs no list: slot k is tile k, and every wave is spared a fetch that its
-        // first arithmetic would have had to wait for)
-        B.tile_list = static_memory || parts <= 1 ? nullptr : be->tile_list;
-        B.tile_place = !static_memory && !be->tile_place_host.empty() ? be->tile_list + be->tile_list_host.size() : nullptr;
-        B.slot0 = slot0;
-        B.n_pixels = slots * tw * th;
-        B.tile_w = tw; B.tile_h = th; B.tiles_x = tiles_x;
-        B.width = ds->width; B.height = ds->height;
-        B.win_x0 = win.x0; B.win_y0 = win.y0; B.win_w = win.w; B.win_h = win.h;
-        B.n = n;
-        B.compact_fb = parts > 1 ? 1u : 0u;
-        B.fused_shadows = fused ? 1u : 0u;
-        B.direct_lit = direct_lit ? 1u : 0u;
-        B.chunked_queue = fuse_camera && fuse_bounce ? 1u : 0u;  // k_camera_shade_packet, then k_bounces_packet
-        B.light_sums_f32 = ref_order ? 0u : 1u;
-        B.aa_method = args->antialias_method;
-        B.seed = args->seed;
-        if ((args->flags & RT_RENDER_ROW_MAJOR_PIXELS) == 0u) rt_pixel_block(tw, th, spp, B.blk_w_log2, B.blk_h_log2);
-        rt_batch_finish(B);
-        const uint32_t n_samples = B.n_pixels * spp;
-
-        const uint32_t lit_grid = (n_samples + RT_LIT_CHUNK - 1) / RT_LIT_CHUNK;
-        // Counters and per-chunk lit counts start at zero.  A backend's batches take turns with two sets of
-        // them: where the batch's first kernel is a camera-ray packet kernel, that kernel zeroes the set the
-        // previous batch used (for the next one), so that no memset stands in front of a frame; any other batch
-        // clears its own set with a memset.  (The static work array is shared by all backends of a device, so
-        // nothing is known about its sets from one call to the next: always a memset.)
-        const uint32_t n_counters = (uint32_t)RT_CNT_SIZE + 2u * lit_grid;  // counters, lit hits per chunk, mirror rays per chunk
-        const bool clear_in_kernel = !ds->has_ggx && !ref_order && use_packets && !static_memory;
+        const RtBatch B = describe_batch(be, ds, args, P, static_memory, slot0, slots);
+        const uint32_t n_samples = B.n_pixels * P.spp;
+        const BatchGrids G = batch_grids(args, n_samples);
         uint32_t n_clear = 0;
-        {
-            uint32_t *const sets[2] = {Q.counters < Q.counters_next ? Q.counters : Q.counters_next,
-                                       Q.counters < Q.counters_next ? Q.counters_next : Q.counters};
-            const uint32_t set_words = (uint32_t)(sets[1] - sets[0]);
-            uint32_t dirty_static[2] = {~0u, ~0u};
-            uint32_t *dirty = static_memory ? dirty_static : be->counter_dirty;
-            // a clean set if there is one and this batch keeps the turns going, else a dirty one (and the memset)
-            int use = 0;
-            if (clear_in_kernel) use = dirty[0] == 0u ? 0 : dirty[1] == 0u ? 1 : 0;
-            else use = dirty[0] == 0u && dirty[1] != 0u ? 1 : 0;
-            if (dirty[use] != 0u) RT_HIP(hipMemsetAsync(sets[use], 0, (size_t)n_counters * sizeof(uint32_t), stream));
-            dirty[use] = std::max(dirty[use], n_counters);
-            if (clear_in_kernel) {
-                n_clear = std::min(dirty[use ^ 1], set_words);
-                dirty[use ^ 1] = 0u;
-            }
-            Q.counters = sets[use];
-            Q.block_counts = Q.counters + RT_CNT_SIZE;
-            Q.mirror_counts = Q.block_counts + lit_grid;
-            Q.counters_next = sets[use ^ 1];
-        }
-        const uint32_t full_grid = (n_samples + RT_BLOCK - 1) / RT_BLOCK;
-        const uint32_t fast_grid = full_grid;  // worst case; blocks without work return at once
-        const uint32_t packet_grid = (n_samples + RT_PACKET_BLOCK * packet_rays - 1) / (RT_PACKET_BLOCK * packet_rays);
-        if (tree_levels && !tree_depth_first) {
+        const bool clear_in_kernel = !ds->has_ggx && !P.ref_order && P.use_packets && !static_memory;
+        if ((rc = take_counter_set(be, Q, G.lit, clear_in_kernel, static_memory, stream, n_clear))) return rc;
+        const bool by_levels = P.tree_levels && !tree_depth_first;
+        if (by_levels) {
             TreeBatch levels;
-            if ((rc = tree_levels_batch(be, ds, args, stream, stats != nullptr, tm, S, Q, B, io, n_samples, camera_lds, packet_lds, bounce_lds, levels)))
-                return rc;
+            if ((rc = tree_levels_batch(be, ds, args, P, stream, stats != nullptr, tm, S, Q, B, io, n_samples, levels))) return rc;
             be->counter_dirty[0] = be->counter_dirty[1] = ~0u;  // the levels took turns with both sets
             if (levels.too_large) {
                 // A level has more rays than the buffers hold: the same tiles again in smaller batches (a ray's numbers
@@ -2171,123 +2353,32 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
             }
             tree_secondary += levels.secondary;
             tree_lit += levels.lit;
-        } else if (ds->has_ggx) {  // one thread per ray tree, depth first: replaces stages 1-5
+        } else if (ds->has_ggx) {  // one thread per ray tree, depth first, instead of the stages
             if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            if (ref_order)
-                hipLaunchKernelGGL((k_render_tree<false>), dim3(full_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, n_samples);
+            if (P.ref_order)
+                hipLaunchKernelGGL((k_render_tree<false>), dim3(G.full), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, B, io, n_samples);
             else
-                hipLaunchKernelGGL((k_render_tree<true>), dim3(full_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, n_samples);
+                hipLaunchKernelGGL((k_render_tree<true>), dim3(G.full), dim3(RT_BLOCK), P.lds_bytes, stream, S, Q, B, io, n_samples);
             tm.end();
-        } else {
-        // chunk of the XCD remap, in 256-sample blocks: 128 (a few tiles) for a whole frame, smaller
-        // for a small launch so that every XCD still gets >= 32 chunks -- chunks differ in cost, and
-        // with only a handful each the XCDs finish far apart (a 1/8 frame: 0.272 -> 0.254 ms)
-        uint32_t xcd_chunk = args->xcd_chunk ? args->xcd_chunk : std::min(128u, std::max(8u, full_grid / 256u));
-        while ((xcd_chunk & (xcd_chunk - 1u)) != 0u) xcd_chunk &= xcd_chunk - 1u;  // down to a power of two: the kernels shift and mask
-        for (int bounce = 0; bounce <= max_bounce; ++bounce) {
-            // bounce 0: one thread per sample.  Later bounces: the queue length is only known on
-            // the device, so a fixed grid strides over it (and costs little when it is empty).
-            const uint32_t g = bounce == 0 ? full_grid : std::min<uint32_t>(full_grid, RT_MAX_GRID);
-            if (bounce > 0 && fuse_bounce) {  // one launch follows the rays of bounce 1 through all later bounces
-                if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                if (use_packets) {  // one resident set of one-wave blocks
-                    // With statistics: one resident set of waves striding over the packets, which hand their ray
-                    // counts to the batch's counters once each.  Without: a wave per packet, dealt by the hardware
-                    // as waves finish (mirror chains differ in length; a fixed deal waits for its unluckiest wave).
-                    const uint32_t gp = stats ? std::min<uint32_t>(packet_grid, 256u * 4u * RT_BOUNCE_PACKET_RESIDENT) : packet_grid;
-                    hipLaunchKernelGGL(k_bounces_packet, dim3(gp), dim3(RT_PACKET_BLOCK), bounce_lds, stream, S, Q, B, io, n_samples, stats ? 1u : 0u, TreeSpawn{});
-                } else {
-                    const uint32_t gb = std::min<uint32_t>(full_grid, RT_BOUNCE_GRID);
-                    hipLaunchKernelGGL(k_bounces_fast, dim3(gb), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, io, xcd_chunk);
-                }
-                tm.end();
-                break;
-            }
-            if (tm.begin(RT_K_TRACE_CLOSEST)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            if (ref_order)
-                hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
-            else if (bounce == 0 && fuse_camera)
-                hipLaunchKernelGGL(k_camera_shade_packet, dim3(packet_grid), dim3(RT_PACKET_BLOCK), camera_lds, stream, S, Q, B, io, n_samples, xcd_chunk, n_clear);
-            else if (bounce == 0 && use_packets)
-                hipLaunchKernelGGL((k_trace_packet<0, 1>), dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, n_clear);
-            else
-                hipLaunchKernelGGL((k_trace_fast<0>), dim3(fast_grid), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, bounce, n_samples, xcd_chunk);
-            tm.end();
-            if (bounce == 0 && fuse_camera) continue;  // the camera-ray kernel has done the stage behind it too
-            if (tm.begin(RT_K_SHADE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-            if (bounce == 0)
-                hipLaunchKernelGGL((k_shade<true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, Q, B, io, 0, n_samples);
-            else
-                hipLaunchKernelGGL((k_shade<false>), dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io, bounce, n_samples);
-            tm.end();
+        } else if ((rc = launch_stages(ds, P, stream, stats != nullptr, tm, S, Q, B, io, n_samples, G, n_clear))) {
+            return rc;
         }
-        if (ds->has_lit) {
-            if (direct_lit) {
-                if (stats) hipLaunchKernelGGL(k_lit_total, dim3(1), dim3(RT_BLOCK), 0, stream, Q, lit_grid);
-            } else {
-                if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                if (lit_grid <= RT_LIT_OWN_OFFSET_MAX) {
-                    hipLaunchKernelGGL((k_lit_scatter<true>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
-                } else {
-                    hipLaunchKernelGGL(k_lit_scan, dim3(1), dim3(RT_LIT_THREADS), 0, stream, Q, lit_grid);
-                    hipLaunchKernelGGL((k_lit_scatter<false>), dim3(lit_grid), dim3(RT_LIT_THREADS), 0, stream, Q, n_samples);
-                }
-                tm.end();
-            }
-            // the number of lit hits is only known on the device: size the grids for the worst
-            // case, surplus blocks return at once
-            if (fused) {
-                if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                hipLaunchKernelGGL(k_shadow_shade_packet, dim3(packet_grid), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, io, xcd_chunk);
-                tm.end();
-            } else {
-                if (!S.disable_shadows && ds->n_point_lights > 0) {
-                    if (tm.begin(RT_K_TRACE_SHADOW)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                    const dim3 sg(full_grid, ds->n_point_lights);
-                    if (ref_order)
-                        hipLaunchKernelGGL((k_trace_shadow<false, false, true>), sg, dim3(RT_BLOCK), lds_bytes, stream, S, Q, xcd_chunk);
-                    else if (use_packets && closest_blockers)
-                        hipLaunchKernelGGL((k_trace_packet<2, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, 0u);
-                    else if (use_packets)
-                        hipLaunchKernelGGL((k_trace_packet<1, 1>), dim3(packet_grid, ds->n_point_lights), dim3(RT_PACKET_BLOCK), packet_lds, stream, S, Q, B, n_samples, xcd_chunk, 0u);
-                    else
-                        hipLaunchKernelGGL((k_trace_fast<1>), dim3(fast_grid, ds->n_point_lights), dim3(RT_BLOCK), lds_bytes, stream, S, Q, B, 0, n_samples, xcd_chunk);
-                    tm.end();
-                }
-                if (tm.begin(RT_K_ACCUMULATE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-                hipLaunchKernelGGL(k_accumulate, dim3(full_grid), dim3(RT_BLOCK), 0, stream, S, Q, B, io);
-                tm.end();
-            }
-        }
-        }
+        // ---- the samples' colours into the pixels
         if (tm.begin(RT_K_RESOLVE)) return rt::set_error(RT_ERR_DEVICE, "hipEventCreate failed");
-        {
-            const dim3 resolve_grid((uint32_t)std::min<uint64_t>(((uint64_t)B.n_pixels + 63u) / 64u, 4u * RT_MAX_GRID));
-            if (rt_resolve_by_pixels(spp)) hipLaunchKernelGGL(k_resolve_pixels, resolve_grid, dim3(RT_RESOLVE_BLOCK), 0, stream, Q, B, fb_dev);
-            else hipLaunchKernelGGL(k_resolve, resolve_grid, dim3(RT_RESOLVE_BLOCK), 0, stream, Q, B, fb_dev);
-        }
+        const dim3 resolve_grid((uint32_t)std::min<uint64_t>(((uint64_t)B.n_pixels + 63u) / 64u, 4u * RT_MAX_GRID));
+        if (rt_resolve_by_pixels(P.spp)) hipLaunchKernelGGL(k_resolve_pixels, resolve_grid, dim3(RT_RESOLVE_BLOCK), 0, stream, Q, B, fb_dev);
+        else hipLaunchKernelGGL(k_resolve, resolve_grid, dim3(RT_RESOLVE_BLOCK), 0, stream, Q, B, fb_dev);
         tm.end();
 
-        if (wait_batches) {
-            if (stats && !(tree_levels && !tree_depth_first)) {  // counters must be read before the next batch clears them
+        if (P.wait_batches) {
+            if (stats && !by_levels) {  // counters must be read before the next batch clears them
                 const size_t at = host_counters.size();
                 host_counters.resize(at + RT_CNT_SIZE);
-                RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, stream));
+                RT_HIP(hipMemcpyAsync(host_counters.data() + at, Q.counters, RT_CNT_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             }
             RT_HIP(hipStreamSynchronize(stream));
-            if (serve_progress) {  // pixels of the owned tiles that lie inside the image, finished / in all
-                auto inside = [&](uint32_t from, uint32_t to) {
-                    uint64_t px = 0;
-                    for (uint32_t k = from; k < to; ++k) {
-                        const uint32_t tile = (uint32_t)be->tile_list_host[k];
-                        const uint32_t x0 = (tile % tiles_x) * tw, y0 = (tile / tiles_x) * th;
-                        px += (uint64_t)std::min(tw, W - x0) * std::min(th, H - y0);
-                    }
-                    return px;
-                };
-                args->progress(inside(0, slot0 + slots), inside(0, n_slots), args->progress_user);
-            }
+            if (P.serve_progress)  // pixels of the owned tiles that lie inside the image, finished / in all
+                args->progress(pixels_inside(be, P, 0, slot0 + slots), pixels_inside(be, P, 0, n_slots), args->progress_user);
         }
         tree_depth_first = false;  // (it was this batch's alone)
     }
@@ -2299,34 +2390,13 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
         tm.pairs.clear();
     }
     if (stats) {
-        RT_HIP(hipEventRecord(ev1, stream));
+        RT_HIP(hipEventRecord(frame_ev.b, stream));
         RT_HIP(hipStreamSynchronize(stream));
         float ms = 0.0f;
-        RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        RT_HIP(hipEventElapsedTime(&ms, frame_ev.a, frame_ev.b));
         stats->render_ms = ms;
         tm.collect(stats);
-        // camera rays = samples of the owned pixels that lie inside the image
-        for (int32_t tile : be->tile_list_host) {
-            const uint32_t x0 = ((uint32_t)tile % tiles_x) * tw, y0 = ((uint32_t)tile / tiles_x) * th;
-            const uint64_t w_in = std::min(tw, W - x0), h_in = std::min(th, H - y0);
-            stats->primary_rays += w_in * h_in * spp;
-        }
-        stats->secondary_rays += tree_secondary;  // ray trees level by level: the levels' own counters
-        stats->shaded_hits += tree_lit;
-        if (!S.disable_shadows) stats->shadow_rays += tree_lit * ds->n_point_lights;
-        for (size_t at = 0; at < host_counters.size(); at += RT_CNT_SIZE) {
-            const uint32_t *c = host_counters.data() + at;
-            if (ds->has_ggx) {
-                auto wide = [&](int at) { return (uint64_t)c[at] | ((uint64_t)c[at + 1] << 32); };
-                stats->secondary_rays += wide(RT_CNT_TREE_SECONDARY);
-                stats->shadow_rays += wide(RT_CNT_TREE_SHADOW);
-                stats->shaded_hits += wide(RT_CNT_TREE_SHADED);
-            } else {
-                for (int b = 1; b <= max_bounce && b < 32; ++b) stats->secondary_rays += c[RT_CNT_RAYS0 + b];
-                stats->shaded_hits += c[RT_CNT_LIT];
-                if (!S.disable_shadows) stats->shadow_rays += (uint64_t)c[RT_CNT_LIT] * ds->n_point_lights;
-            }
-        }
+        add_up_ray_counts(stats, be, ds, P, S, host_counters, tree_secondary, tree_lit);
     }
     // A frame on a stream of the caller's: rt_backend_sync must be able to wait for it without keeping the
     // stream's handle (the caller may destroy the stream), so an event of the backend's marks its end.
