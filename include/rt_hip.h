@@ -175,7 +175,7 @@ typedef struct RtRenderArgs {
     /* Tuning; 0 = the library's choice everywhere.  None of them changes a pixel (RT_RENDER_TREE_DEPTH_FIRST, for
      * scenes with a GGXMirror shader, changes colours in the last places of an f32: see there).
      *  batch_samples  most samples (pixels x rays per pixel) worked on at a time; a larger frame is
-     *                 rendered in several batches of whole tiles (0 -> 32 Mi, about 8.5 GB of work buffers)
+     *                 rendered in several batches of whole tiles (0 -> 32 Mi, about 8.5 GB of work buffers; at most 2^30)
      *  xcd_chunk      consecutive 256-sample blocks handed to one XCD (one L2) at a time (rounded down to a power of two)
      *  flags          RT_RENDER_* below */
     uint32_t batch_samples;

@@ -2253,7 +2253,8 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     // ---- tiles per batch, and work memory for a batch
     // (32 Mi samples, 8.5 GB of work buffers with two point lights: the 3840 x 2160 frame at 64 rays per pixel takes
     // 36.3 ms in batches of 16 Mi, 35.4 of 32 Mi, 34.9 of 64 Mi -- fewer, larger launches, fewer kernel tails)
-    const uint64_t max_batch = args->batch_samples ? args->batch_samples : (32ull << 20);
+    // (at most 2^30: samples are numbered in 32 bits, signed where an index doubles as a flag)
+    const uint64_t max_batch = std::min<uint64_t>(args->batch_samples ? args->batch_samples : (32ull << 20), 1ull << 30);
     uint32_t slots_per_batch = (uint32_t)std::max<uint64_t>(1, max_batch / P.tile_samples);
     if (static_memory && (rc = static_batch_slots(ds, P, std::min<uint64_t>(slots_per_batch, std::max<uint32_t>(n_slots, 1)), slots_per_batch)))
         return rc;
