@@ -93,18 +93,24 @@ def scenes(tmp_dir):
             light=[{"_type": "point", "position": "5.0 -0.99999 2.0", "intensity": "0.6 0.6 0.6"},
                    {"_type": "point", "position": "-4.0 -0.9999999 3.0", "intensity": "0.5 0.5 0.5"},
                    POINT]), 96, 72, 2),
+        # More point lights than the fused shadow kernel has bits for (32): the fast mode then goes through the separate
+        # shadow and light-sum kernels; with a mirror in view, so that lit hits behind a bounce take that way too.
+        "forty_lights": (_scene(shape=BALLS + [{"_name": "m", "_type": "sphere", "shader": "mir", "center": "0.2 1.4 -1.0", "radius": 0.7}],
+                                light=[{"_type": "point", "position": f"{-5 + 0.25 * k:.2f} {3 + 0.05 * (k % 7):.2f} {4 - 0.2 * (k % 5):.2f}",
+                                        "intensity": "0.03 0.03 0.03"} for k in range(40)] + [AMBIENT]), 64, 48, 2),
     }
     return {k: (json.dumps(v[0]), tmp_dir) + v[1:] for k, v in out.items()}
 
 
 NAMES = ["no_lights", "ambient_only", "one_shape", "one_pixel", "wide_aspect", "odd_size_many_samples", "camera_inside_box",
-         "mirror_pair", "degenerate_mesh", "half_flat_mesh", "scaled_instances", "boxes_grazing_lights"]
+         "mirror_pair", "degenerate_mesh", "half_flat_mesh", "scaled_instances", "boxes_grazing_lights", "forty_lights"]
 
 
-def ggx_scene(roughness=0.25, samples=3, mirror_type=None):
+def ggx_scene(roughness=0.25, samples=3, mirror_type=None, point_lights=None):
     """Two rough mirrors (GGXMirror, ggx_mirror.rs) facing each other and a perfect mirror, over a lit floor
     and a lit ball: GGX hits under GGX hits, GGX under a mirror, lit hits at every depth.  With
-    `mirror_type` the rough shader is replaced by that type (for comparisons)."""
+    `mirror_type` the rough shader is replaced by that type (for comparisons); `point_lights` replaces the two
+    point lights."""
     rough = ({"_name": "rough", "_type": "GGXMirror", "roughness": roughness, "samples": samples} if mirror_type is None
              else {"_name": "rough", "_type": mirror_type})
     shaders = SHADERS + [rough]
@@ -117,7 +123,7 @@ def ggx_scene(roughness=0.25, samples=3, mirror_type=None):
         BALLS[2],
     ]
     return json.dumps({"scene": {"camera": CAM, "shader": shaders, "shape": shapes,
-                                 "light": [POINT, {"_type": "point", "position": "-4 2.5 3", "intensity": "0.5 0.5 0.6"}, AMBIENT],
+                                 "light": (point_lights or [POINT, {"_type": "point", "position": "-4 2.5 3", "intensity": "0.5 0.5 0.6"}]) + [AMBIENT],
                                  "sceneParameters": {"bgColor": "0.2 0.25 0.35"}}})
 
 

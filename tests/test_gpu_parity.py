@@ -925,6 +925,24 @@ def test_ggx_matches_committed_fixture(rt, backend):
     dev.close()
 
 
+def test_ggx_with_more_point_lights_than_the_fused_kernel_holds(rt, backend):
+    """Ray trees level by level ride on the fused shadow kernel, which keeps a bit per point light in one word: a scene
+    with 40 lights goes depth first in fast mode too, and must match the oracle like any other."""
+    lights = [{"_type": "point", "position": f"{-5 + 0.25 * k:.2f} {3 + 0.05 * (k % 7):.2f} {4 - 0.2 * (k % 5):.2f}",
+               "intensity": "0.03 0.03 0.03"} for k in range(40)]
+    scene = rt.parse_scene(edge_scenes.ggx_scene(point_lights=lights), "", image_width=64, image_height=48, recursion_depth=3)
+    dev = backend.upload(scene)
+    ref_fb, ref_ids, counters = oracle_lib.render(scene, 2, seed=7)
+    for mode in (rt.RT_MODE_FAST, rt.RT_MODE_REFERENCE_ORDER):
+        fb, ids, stats = dev.render(2, mode=mode, want_ids=True, seed=7)
+        m = parity.image_metrics(fb.pixels, ref_fb)
+        assert m["lsb1_fraction"] >= parity.LSB_MATCH_MIN and m["psnr_db"] >= parity.PSNR_MIN_DB, m
+        assert (ids.primary_shape == ref_ids.primary_shape).mean() >= 0.9999
+        for g, r in zip([stats.primary_rays, stats.secondary_rays, stats.shadow_rays], counters["rays"]):
+            assert abs(g - r) <= max(4, r // 2000), (stats, counters["rays"])
+    dev.close()
+
+
 def test_ggx_limits(rt, backend):
     """Roughness 0 with one sample is a perfect mirror; trees deeper than the kernel's frame stack
     are refused, not truncated."""
