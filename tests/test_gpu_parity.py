@@ -971,6 +971,21 @@ def test_invalid_arguments_are_errors(rt, backend, scene_path):
     assert e.value.code == rt.RT_ERR_INVALID
     with pytest.raises(rt.RtError):
         dev.render(2, part=(3, 2))
+    # every refusal of the frame's plan: a window that sticks out or comes with a split, spans that do not fit
+    for kw, what in [(dict(window=(20, 0, 16, 8)), "sticks out"), (dict(window=(0, 30, 4, 4)), "sticks out"),
+                     (dict(window=(0, 0, 8, 8), part=(0, 2)), "rendered whole"), (dict(part=(0, 2), part_span=3), "part_span exceeds"),
+                     (dict(part=(0, 2), part0_weight=9), "part0_weight"), (dict(mode=7), "traversal mode"), (dict(tile=(1 << 15, 1 << 15)), "tile too large")]:
+        with pytest.raises(rt.RtError) as e:
+            dev.render(2, **kw)
+        assert e.value.code == rt.RT_ERR_INVALID and what in str(e.value), (kw, str(e.value))
+    import torch
+
+    fb_dev = torch.zeros(32 * 32 * 3, dtype=torch.float32, device="cuda")
+    for kw, what in [(dict(part=(0, 4), part_span=2, part_span_pitch_floats=100), "whole number of tiles"),
+                     (dict(part=(0, 4), tile=(8, 8), part_span=2, part_span_pitch_floats=8 * 8 * 3), "smaller than a part")]:
+        with pytest.raises(rt.RtError) as e:
+            dev.render_device(dev.render_args(2, **kw), fb_dev.data_ptr())
+        assert e.value.code == rt.RT_ERR_INVALID and what in str(e.value), (kw, str(e.value))
     fb, _, _ = dev.render(1)  # the backend is still usable after errors
     assert fb.pixels.any()
     dev.close()
