@@ -38,9 +38,51 @@ def describe(name, t0, t1, slots):
         overlap = np.clip(np.minimum(t1, b) - np.maximum(t0, a), 0, None).sum() / (b - a)
         occ.append(overlap)
     print("   resident waves per twentieth of the span:", " ".join(f"{o:.0f}" for o in occ))
+    # the longest waves: when they start (a wave that starts late and runs long is the kernel's tail)
+    top = np.argsort(dur)[-8:][::-1]
+    print("   longest waves (start us, duration us, index):", " ".join(f"({t0[i] / 1e3:.0f}, {dur[i] / 1e3:.0f}, {i})" for i in top))
     # when the last wave STARTS, and what runs after that
     print(f"   last start at {t0.max() / 1e3:.1f} us; waves still running 10/20/40 us before the end: "
           f"{(t1 > end - 10000).sum()} {(t1 > end - 20000).sum()} {(t1 > end - 40000).sum()}")
+
+
+def simulate(name, dur, order, slots):
+    """List scheduling of the measured wave durations on `slots` wave slots in the given order: the span a kernel
+    would have with its waves started in that order (durations as measured, i.e. under the contention of this run)."""
+    import heapq
+
+    free = [0.0] * slots
+    heapq.heapify(free)
+    end = 0.0
+    for i in order:
+        t = heapq.heappop(free) + dur[i]
+        end = max(end, t)
+        heapq.heappush(free, t)
+    print(f"   simulated span, {name}: {end / 1e3:.1f} us")
+
+
+def orders(cam, sh, slots):
+    """What the shadow kernel's span would be with its packets started in another order: as they were, longest first
+    (unknowable), and the chunks of 16 packets in the order of what the camera-ray waves of the same chunk cost."""
+    import numpy as np
+
+    live = sh[:, 1] > 0
+    idx = np.nonzero(live)[0]
+    t0 = (sh[idx, 0] - sh[idx, 0].min()) * 10.0
+    dur = (sh[idx, 1] - sh[idx, 0]) * 10.0
+    simulate("as started", dur, np.argsort(t0, kind="stable"), slots)
+    simulate("longest first (an oracle)", dur, np.argsort(-dur, kind="stable"), slots)
+    cam_dur = np.where(cam[:, 1] > 0, (cam[:, 1] - cam[:, 0]) * 10.0, 0.0)
+    n_chunks = -(-cam.shape[0] // 16)
+    cost = np.zeros(n_chunks)
+    np.add.at(cost, np.arange(cam.shape[0]) // 16, cam_dur)
+    chunk_of = idx // 16
+    simulate("chunks by their camera waves' time, dearest first", dur, np.lexsort((t0, -cost[chunk_of])), slots)
+    heavy = cost[chunk_of] > 3.0 * cost.mean()
+    simulate("chunks above 3x the mean camera time first, the rest as started", dur, np.lexsort((t0, ~heavy)), slots)
+    own = np.zeros(n_chunks)
+    np.add.at(own, chunk_of, dur)
+    simulate("chunks by their own shadow waves' time (an oracle per chunk)", dur, np.lexsort((t0, -own[chunk_of])), slots)
 
 
 def main():
@@ -81,6 +123,7 @@ def main():
     print(f"{workload}, part {part} of {parts}: {packets} packets")
     describe("camera rays + shade", cam[:, 0], cam[:, 1], 1024 * 7)
     describe("shadow rays + light sums", sh[:, 0], sh[:, 1], 1024 * 8)
+    orders(cam, sh, 1024 * 8)
     both0 = np.concatenate([cam[:, 0], sh[:, 0]])
     both1 = np.concatenate([cam[:, 1], sh[:, 1]])
     describe("both kernels", both0, both1, 1024 * 8)
