@@ -1636,6 +1636,15 @@ int check_partition(const RtRenderArgs *args) {
     return RT_OK;
 }
 
+// The tiles laid over W x H pixels.  At most 2^26 of them: tiles are numbered in 32 bits and listed on the host.
+int tile_grid(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t &tiles_x, uint32_t &tiles_y) {
+    const uint64_t tx = ((uint64_t)W + tw - 1) / tw, ty = ((uint64_t)H + th - 1) / th;
+    if (tx * ty > (1ull << 26)) return rt::set_error(RT_ERR_INVALID, "frame too large: more than 2^26 tiles (use larger tiles)");
+    tiles_x = (uint32_t)tx;
+    tiles_y = (uint32_t)ty;
+    return RT_OK;
+}
+
 typedef RtEventPair EventPair;
 
 struct Timing {
@@ -1784,8 +1793,7 @@ int plan_frame(const RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     if (int bad = resolve_window(args, ds->width, ds->height, P.win)) return bad;
     P.W = P.win.w;
     P.H = P.win.h;
-    P.tiles_x = (P.W + P.tw - 1) / P.tw;
-    P.tiles_y = (P.H + P.th - 1) / P.th;
+    if (int bad = tile_grid(P.W, P.H, P.tw, P.th, P.tiles_x, P.tiles_y)) return bad;
     P.spp = P.n * P.n;
     P.tile_samples = (uint64_t)P.tw * P.th * P.spp;
     if (P.tile_samples > (1ull << 30)) return rt::set_error(RT_ERR_INVALID, "tile too large");
@@ -2223,8 +2231,8 @@ void add_up_ray_counts(RtStats *stats, const RtBackend *be, const RtDeviceScene 
 
 }  // namespace
 
-int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
-                     hipStream_t stream, RtStats *stats, bool blocking, bool static_memory) {
+static int render_frame_body(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
+                             hipStream_t stream, RtStats *stats, bool blocking, bool static_memory) {
     FramePlan P;
     if (int bad = plan_frame(be, ds, args, fb_dev, stats != nullptr, blocking, static_memory, P)) return bad;
     RT_HIP(hipSetDevice(be->device));
@@ -2411,6 +2419,12 @@ int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs 
     return rc;
 }
 
+// (what every render entry point, and the worker threads of rt_render_multi, go through)
+int rt::render_frame(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_dev, const RtRayIds *ids,
+                     hipStream_t stream, RtStats *stats, bool blocking, bool static_memory) {
+    return rt::guarded([&]() -> int { return render_frame_body(be, ds, args, fb_dev, ids, stream, stats, blocking, static_memory); });
+}
+
 // ------------------------------------------------------------------ C ABI
 
 extern "C" const char *rt_last_error(void) { return rt::last_error_slot().c_str(); }
@@ -2424,39 +2438,41 @@ extern "C" int rt_debug_wave_log(void *log_dev) {
 #endif
 
 extern "C" int rt_backend_create(int device_ordinal, RtBackend **backend_out) {
-    if (!backend_out) return rt::set_error(RT_ERR_INVALID, "null argument");
-    *backend_out = nullptr;
-    int count = 0;
-    RT_HIP(hipGetDeviceCount(&count));
-    if (device_ordinal < 0 || device_ordinal >= count)
-        return rt::set_error(RT_ERR_DEVICE, "no HIP device with ordinal " + std::to_string(device_ordinal));
-    RT_HIP(hipSetDevice(device_ordinal));
-    RtBackend *be = new RtBackend();
-    be->device = device_ordinal;
-    hipError_t e = hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&be->sticky, 256);
-    if (e == hipSuccess) e = hipMemset(be->sticky, 0, 256);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&be->sticky_host, 64, hipHostMallocDefault);
-    // the device address of this device's copy of the static work array (this device is current)
-    if (e == hipSuccess) e = hipGetSymbolAddress((void **)&be->scratch, HIP_SYMBOL(scratch));
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&be->foreign_done, hipEventDisableTiming);
-    if (e == hipSuccess) {
-        if (device_ordinal < RT_STATIC_MAX_DEVICES) {
-            static std::mutex mu;
-            std::lock_guard<std::mutex> lock(mu);
-            StaticSlot &slot = static_slot(device_ordinal);
-            if (!slot.done) e = hipEventCreateWithFlags(&slot.done, hipEventDisableTiming);
-        } else {
-            be->scratch = nullptr;  // rt_render_device_static then reports that it is not available
+    return rt::guarded([&]() -> int {
+        if (!backend_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+        *backend_out = nullptr;
+        int count = 0;
+        RT_HIP(hipGetDeviceCount(&count));
+        if (device_ordinal < 0 || device_ordinal >= count)
+            return rt::set_error(RT_ERR_DEVICE, "no HIP device with ordinal " + std::to_string(device_ordinal));
+        RT_HIP(hipSetDevice(device_ordinal));
+        RtBackend *be = new RtBackend();
+        be->device = device_ordinal;
+        hipError_t e = hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&be->sticky, 256);
+        if (e == hipSuccess) e = hipMemset(be->sticky, 0, 256);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&be->sticky_host, 64, hipHostMallocDefault);
+        // the device address of this device's copy of the static work array (this device is current)
+        if (e == hipSuccess) e = hipGetSymbolAddress((void **)&be->scratch, HIP_SYMBOL(scratch));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&be->foreign_done, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            if (device_ordinal < RT_STATIC_MAX_DEVICES) {
+                static std::mutex mu;
+                std::lock_guard<std::mutex> lock(mu);
+                StaticSlot &slot = static_slot(device_ordinal);
+                if (!slot.done) e = hipEventCreateWithFlags(&slot.done, hipEventDisableTiming);
+            } else {
+                be->scratch = nullptr;  // rt_render_device_static then reports that it is not available
+            }
         }
-    }
-    if (e != hipSuccess) {
-        rt_backend_destroy(be);
-        return rt::set_error(RT_ERR_DEVICE, std::string("backend set-up: ") + hipGetErrorString(e));
-    }
-    *be->sticky_host = 0u;
-    *backend_out = be;
-    return RT_OK;
+        if (e != hipSuccess) {
+            rt_backend_destroy(be);
+            return rt::set_error(RT_ERR_DEVICE, std::string("backend set-up: ") + hipGetErrorString(e));
+        }
+        *be->sticky_host = 0u;
+        *backend_out = be;
+        return RT_OK;
+    });
 }
 
 extern "C" void rt_backend_destroy(RtBackend *be) {
@@ -2484,20 +2500,24 @@ extern "C" void rt_backend_destroy(RtBackend *be) {
 }
 
 extern "C" int rt_backend_sync(RtBackend *be) {
-    if (!be) return rt::set_error(RT_ERR_INVALID, "null argument");
-    RT_HIP(hipSetDevice(be->device));
-    if (be->foreign_pending) {  // frames that went to a stream of the caller's: their end is marked by an event
-        RT_HIP(hipStreamWaitEvent(be->stream, be->foreign_done, 0));
-        be->foreign_pending = false;
-    }
-    return rt::finish_stream(be, be->stream);
+    return rt::guarded([&]() -> int {
+        if (!be) return rt::set_error(RT_ERR_INVALID, "null argument");
+        RT_HIP(hipSetDevice(be->device));
+        if (be->foreign_pending) {  // frames that went to a stream of the caller's: their end is marked by an event
+            RT_HIP(hipStreamWaitEvent(be->stream, be->foreign_done, 0));
+            be->foreign_pending = false;
+        }
+        return rt::finish_stream(be, be->stream);
+    });
 }
 
 extern "C" int rt_host_alloc(size_t bytes, void **ptr_out) {
-    if (!ptr_out) return rt::set_error(RT_ERR_INVALID, "null argument");
-    *ptr_out = nullptr;
-    RT_HIP(hipHostMalloc(ptr_out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
-    return RT_OK;
+    return rt::guarded([&]() -> int {
+        if (!ptr_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+        *ptr_out = nullptr;
+        RT_HIP(hipHostMalloc(ptr_out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+        return RT_OK;
+    });
 }
 
 extern "C" void rt_host_free(void *ptr) {
@@ -2509,77 +2529,79 @@ extern "C" int rt_scene_upload(RtBackend *be, const RtScene *scene, RtDeviceScen
 }
 
 extern "C" int rt_scene_upload_with(RtBackend *be, const RtScene *scene, const RtUploadOptions *options, RtDeviceScene **out) {
-    if (!be || !scene || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
-    *out = nullptr;
-    const uint32_t upload_flags = options ? options->flags : 0u;
-    if (upload_flags & ~(uint32_t)RT_UPLOAD_REFERENCE_MESH_TREES) return rt::set_error(RT_ERR_INVALID, "unknown upload flag");
-    bool uses_ggx = false;
-    for (uint32_t s = 0; s < scene->n_shapes; ++s) {
-        const int32_t sh = scene->shapes[s].shader;
-        uses_ggx = uses_ggx || (sh >= 0 && (uint32_t)sh < scene->n_shaders && scene->shaders[sh].type == RT_SHADER_GGX_MIRROR);
-    }
-    if (uses_ggx && scene->recursion_depth > RT_TREE_MAX_DEPTH)
-        return rt::set_error(RT_ERR_UNSUPPORTED, "GGXMirror with a recursion depth above " + std::to_string(RT_TREE_MAX_DEPTH));
-    rt::FlatScene flat;
-    const std::string err = rt::flatten_scene(*scene, flat, (upload_flags & RT_UPLOAD_REFERENCE_MESH_TREES) != 0u);
-    if (!err.empty()) return rt::set_error(RT_ERR_INVALID, err);
-    RT_HIP(hipSetDevice(be->device));
+    return rt::guarded([&]() -> int {
+        if (!be || !scene || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
+        *out = nullptr;
+        const uint32_t upload_flags = options ? options->flags : 0u;
+        if (upload_flags & ~(uint32_t)RT_UPLOAD_REFERENCE_MESH_TREES) return rt::set_error(RT_ERR_INVALID, "unknown upload flag");
+        bool uses_ggx = false;
+        for (uint32_t s = 0; s < scene->n_shapes; ++s) {
+            const int32_t sh = scene->shapes[s].shader;
+            uses_ggx = uses_ggx || (sh >= 0 && (uint32_t)sh < scene->n_shaders && scene->shaders[sh].type == RT_SHADER_GGX_MIRROR);
+        }
+        if (uses_ggx && scene->recursion_depth > RT_TREE_MAX_DEPTH)
+            return rt::set_error(RT_ERR_UNSUPPORTED, "GGXMirror with a recursion depth above " + std::to_string(RT_TREE_MAX_DEPTH));
+        rt::FlatScene flat;
+        const std::string err = rt::flatten_scene(*scene, flat, (upload_flags & RT_UPLOAD_REFERENCE_MESH_TREES) != 0u);
+        if (!err.empty()) return rt::set_error(RT_ERR_INVALID, err);
+        RT_HIP(hipSetDevice(be->device));
 
-    RtDeviceScene *ds = new RtDeviceScene();
-    ds->backend = be;
-    ds->device = be->device;
-    auto fail = [&](int rc) {
-        free_all(ds->allocs);
-        delete ds;
-        return rc;
-    };
-    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
-        void *p = nullptr;
-        RT_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
-        ds->allocs.push_back(p);
-        if (bytes) RT_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
-        *dst = p;
+        RtDeviceScene *ds = new RtDeviceScene();
+        ds->backend = be;
+        ds->device = be->device;
+        auto fail = [&](int rc) {
+            free_all(ds->allocs);
+            delete ds;
+            return rc;
+        };
+        auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+            void *p = nullptr;
+            RT_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+            ds->allocs.push_back(p);
+            if (bytes) RT_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+            *dst = p;
+            return RT_OK;
+        };
+        RtSceneView &V = ds->view;
+        std::vector<int32_t> point_lights;
+        for (uint32_t i = 0; i < scene->n_lights; ++i)
+            if (scene->lights[i].type == RT_LIGHT_POINT) point_lights.push_back((int32_t)i);
+        int rc;
+        if ((rc = up(flat.nodes.data(), flat.nodes.size() * sizeof(RtNode), (const void **)&V.nodes))) return fail(rc);
+        if ((rc = up(flat.tprims.data(), flat.tprims.size() * sizeof(RtTPrim), (const void **)&V.tprims))) return fail(rc);
+        if ((rc = up(flat.tris.data(), flat.tris.size() * sizeof(RtTri), (const void **)&V.tris))) return fail(rc);
+        if ((rc = up(flat.tri_xf.data(), flat.tri_xf.size() * sizeof(RtTriXf), (const void **)&V.tri_xf))) return fail(rc);
+        if ((rc = up(flat.tprim_xf.data(), flat.tprim_xf.size() * sizeof(float), (const void **)&V.tprim_xf))) return fail(rc);
+        if ((rc = up(scene->shapes, scene->n_shapes * sizeof(RtShape), (const void **)&V.shapes))) return fail(rc);
+        if ((rc = up(scene->protos, scene->n_protos * sizeof(RtShape), (const void **)&V.protos))) return fail(rc);
+        if ((rc = up(flat.verts64.data(), flat.verts64.size() * sizeof(double), (const void **)&V.verts64))) return fail(rc);
+        if ((rc = up(flat.mesh_tri_base.data(), flat.mesh_tri_base.size() * sizeof(uint64_t), (const void **)&V.mesh_tri_base))) return fail(rc);
+        if ((rc = up(scene->shaders, scene->n_shaders * sizeof(RtShader), (const void **)&V.shaders))) return fail(rc);
+        if ((rc = up(scene->lights, scene->n_lights * sizeof(RtLight), (const void **)&V.lights))) return fail(rc);
+        if ((rc = up(point_lights.data(), point_lights.size() * sizeof(int32_t), (const void **)&V.point_lights))) return fail(rc);
+        V.camera = scene->camera;
+        std::memcpy(V.background, scene->background, sizeof(V.background));
+        V.n_lights = (int32_t)scene->n_lights;
+        V.n_point_lights = (int32_t)point_lights.size();
+        V.tlas_root = flat.tlas_root;
+        V.recursion_depth = scene->recursion_depth;
+        V.disable_shadows = scene->disable_shadows;
+        V.stack_depth = flat.stack_depth;
+        ds->view_fast = V;
+        ds->view_fast.tlas_root = flat.tlas_root_fast;
+        ds->view_fast.stack_depth = flat.stack_depth_fast;
+        ds->width = scene->image_width;
+        ds->height = scene->image_height;
+        ds->n_point_lights = (uint32_t)point_lights.size();
+        for (uint32_t s = 0; s < scene->n_shapes; ++s) {
+            const int32_t t = scene->shaders[scene->shapes[s].shader].type;
+            ds->has_mirror = ds->has_mirror || t == RT_SHADER_PERFECT_MIRROR;
+            ds->has_lit = ds->has_lit || t == RT_SHADER_LAMBERTIAN || t == RT_SHADER_BLINN_PHONG;
+        }
+        ds->has_ggx = uses_ggx;
+        *out = ds;
         return RT_OK;
-    };
-    RtSceneView &V = ds->view;
-    std::vector<int32_t> point_lights;
-    for (uint32_t i = 0; i < scene->n_lights; ++i)
-        if (scene->lights[i].type == RT_LIGHT_POINT) point_lights.push_back((int32_t)i);
-    int rc;
-    if ((rc = up(flat.nodes.data(), flat.nodes.size() * sizeof(RtNode), (const void **)&V.nodes))) return fail(rc);
-    if ((rc = up(flat.tprims.data(), flat.tprims.size() * sizeof(RtTPrim), (const void **)&V.tprims))) return fail(rc);
-    if ((rc = up(flat.tris.data(), flat.tris.size() * sizeof(RtTri), (const void **)&V.tris))) return fail(rc);
-    if ((rc = up(flat.tri_xf.data(), flat.tri_xf.size() * sizeof(RtTriXf), (const void **)&V.tri_xf))) return fail(rc);
-    if ((rc = up(flat.tprim_xf.data(), flat.tprim_xf.size() * sizeof(float), (const void **)&V.tprim_xf))) return fail(rc);
-    if ((rc = up(scene->shapes, scene->n_shapes * sizeof(RtShape), (const void **)&V.shapes))) return fail(rc);
-    if ((rc = up(scene->protos, scene->n_protos * sizeof(RtShape), (const void **)&V.protos))) return fail(rc);
-    if ((rc = up(flat.verts64.data(), flat.verts64.size() * sizeof(double), (const void **)&V.verts64))) return fail(rc);
-    if ((rc = up(flat.mesh_tri_base.data(), flat.mesh_tri_base.size() * sizeof(uint64_t), (const void **)&V.mesh_tri_base))) return fail(rc);
-    if ((rc = up(scene->shaders, scene->n_shaders * sizeof(RtShader), (const void **)&V.shaders))) return fail(rc);
-    if ((rc = up(scene->lights, scene->n_lights * sizeof(RtLight), (const void **)&V.lights))) return fail(rc);
-    if ((rc = up(point_lights.data(), point_lights.size() * sizeof(int32_t), (const void **)&V.point_lights))) return fail(rc);
-    V.camera = scene->camera;
-    std::memcpy(V.background, scene->background, sizeof(V.background));
-    V.n_lights = (int32_t)scene->n_lights;
-    V.n_point_lights = (int32_t)point_lights.size();
-    V.tlas_root = flat.tlas_root;
-    V.recursion_depth = scene->recursion_depth;
-    V.disable_shadows = scene->disable_shadows;
-    V.stack_depth = flat.stack_depth;
-    ds->view_fast = V;
-    ds->view_fast.tlas_root = flat.tlas_root_fast;
-    ds->view_fast.stack_depth = flat.stack_depth_fast;
-    ds->width = scene->image_width;
-    ds->height = scene->image_height;
-    ds->n_point_lights = (uint32_t)point_lights.size();
-    for (uint32_t s = 0; s < scene->n_shapes; ++s) {
-        const int32_t t = scene->shaders[scene->shapes[s].shader].type;
-        ds->has_mirror = ds->has_mirror || t == RT_SHADER_PERFECT_MIRROR;
-        ds->has_lit = ds->has_lit || t == RT_SHADER_LAMBERTIAN || t == RT_SHADER_BLINN_PHONG;
-    }
-    ds->has_ggx = uses_ggx;
-    *out = ds;
-    return RT_OK;
+    });
 }
 
 extern "C" void rt_scene_free(RtDeviceScene *ds) {
@@ -2591,22 +2613,24 @@ extern "C" void rt_scene_free(RtDeviceScene *ds) {
 }
 
 extern "C" int rt_collect_timings(RtBackend *be, RtStats *out) {
-    if (!be || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
-    std::memset(out, 0, sizeof(*out));
-    if (be->deferred.empty()) return RT_OK;
-    RT_HIP(hipSetDevice(be->device));
-    RT_HIP(hipStreamSynchronize(be->deferred_stream));
-    for (auto &p : be->deferred) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            out->kernel_ms[p.klass] += ms;
-            out->kernel_launches[p.klass] += 1;
+    return rt::guarded([&]() -> int {
+        if (!be || !out) return rt::set_error(RT_ERR_INVALID, "null argument");
+        std::memset(out, 0, sizeof(*out));
+        if (be->deferred.empty()) return RT_OK;
+        RT_HIP(hipSetDevice(be->device));
+        RT_HIP(hipStreamSynchronize(be->deferred_stream));
+        for (auto &p : be->deferred) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                out->kernel_ms[p.klass] += ms;
+                out->kernel_launches[p.klass] += 1;
+            }
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
         }
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
-    }
-    be->deferred.clear();
-    return RT_OK;
+        be->deferred.clear();
+        return RT_OK;
+    });
 }
 
 extern "C" uint32_t rt_scene_point_light_count(const RtDeviceScene *ds) { return ds ? ds->n_point_lights : 0; }
@@ -2622,248 +2646,267 @@ extern "C" int rt_render_device_static(RtBackend *be, const RtDeviceScene *ds, c
 }
 
 extern "C" int rt_render_async(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb_pinned) {
-    if (!be || !ds || !args || !fb_rgb_pinned) return rt::set_error(RT_ERR_INVALID, "null argument");
-    if (args->part_count > 1) return rt::set_error(RT_ERR_INVALID, "rt_render_async renders whole frames (part_count <= 1)");
-    RT_HIP(hipSetDevice(be->device));
-    if (!rt::is_pinned_host(fb_rgb_pinned))
-        return rt::set_error(RT_ERR_INVALID, "rt_render_async needs page-locked host memory (rt_host_alloc)");
-    Window win;
-    if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
-    const size_t fb_floats = (size_t)win.w * win.h * 3;
-    if (int grown = rt::ensure_device_fb(be, fb_floats)) return grown;
-    if (int rc = rt::render_frame(be, ds, args, be->fb, nullptr, be->stream, nullptr, false, false)) return rc;
-    RT_HIP(hipMemcpyAsync(fb_rgb_pinned, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream));
-    return RT_OK;
+    return rt::guarded([&]() -> int {
+        if (!be || !ds || !args || !fb_rgb_pinned) return rt::set_error(RT_ERR_INVALID, "null argument");
+        if (args->part_count > 1) return rt::set_error(RT_ERR_INVALID, "rt_render_async renders whole frames (part_count <= 1)");
+        RT_HIP(hipSetDevice(be->device));
+        if (!rt::is_pinned_host(fb_rgb_pinned))
+            return rt::set_error(RT_ERR_INVALID, "rt_render_async needs page-locked host memory (rt_host_alloc)");
+        Window win;
+        if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
+        const size_t fb_floats = (size_t)win.w * win.h * 3;
+        if (int grown = rt::ensure_device_fb(be, fb_floats)) return grown;
+        if (int rc = rt::render_frame(be, ds, args, be->fb, nullptr, be->stream, nullptr, false, false)) return rc;
+        RT_HIP(hipMemcpyAsync(fb_rgb_pinned, be->fb, fb_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream));
+        return RT_OK;
+    });
 }
 
 extern "C" int rt_render(RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, float *fb_rgb,
                          const RtRayIds *ids_host, RtStats *stats_out) {
-    if (!be || !ds || !args || !fb_rgb) return rt::set_error(RT_ERR_INVALID, "null argument");
-    RT_HIP(hipSetDevice(be->device));
-    Window win;
-    if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
-    const size_t W = win.w, H = win.h;  // the rendered pixels: what the outputs cover
-    const size_t n = args->sqrt_rays_per_pixel;
-    const size_t samples = W * H * n * n;
-    const size_t fb_floats = W * H * 3;
-    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    const uint32_t tiles_x = ((uint32_t)W + tw - 1) / tw, tiles_y = ((uint32_t)H + th - 1) / th;
-    // a partitioned render lands tile-major (edge tiles padded), so size for whole tiles
-    size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
-    if (parts > 1 && args->part_span > 1) {  // the span's blocks, a pitch apart
-        const std::vector<uint32_t> counts = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight <= 8 ? args->part0_weight : 0);
-        const size_t pitch = args->part_span_pitch_floats ? (size_t)args->part_span_pitch_floats
-                                                          : (size_t)*std::max_element(counts.begin(), counts.end()) * tw * th * 3;
-        dev_floats = std::max(dev_floats, pitch * args->part_span);
-    }
-    if (int grown = rt::ensure_device_fb(be, dev_floats)) return grown;
+    return rt::guarded([&]() -> int {
+        if (!be || !ds || !args || !fb_rgb) return rt::set_error(RT_ERR_INVALID, "null argument");
+        RT_HIP(hipSetDevice(be->device));
+        Window win;
+        if (int bad = resolve_window(args, ds->width, ds->height, win)) return bad;
+        const size_t W = win.w, H = win.h;  // the rendered pixels: what the outputs cover
+        const size_t n = args->sqrt_rays_per_pixel;
+        const size_t samples = W * H * n * n;
+        const size_t fb_floats = W * H * 3;
+        const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+        const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+        uint32_t tiles_x, tiles_y;
+        if (int bad = tile_grid((uint32_t)W, (uint32_t)H, tw, th, tiles_x, tiles_y)) return bad;
+        // a partitioned render lands tile-major (edge tiles padded), so size for whole tiles
+        size_t dev_floats = std::max(fb_floats, (size_t)tiles_x * tiles_y * tw * th * 3);
+        if (parts > 1 && args->part_span > 1) {  // the span's blocks, a pitch apart
+            const std::vector<uint32_t> counts = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight <= 8 ? args->part0_weight : 0);
+            const size_t pitch = args->part_span_pitch_floats ? (size_t)args->part_span_pitch_floats
+                                                              : (size_t)*std::max_element(counts.begin(), counts.end()) * tw * th * 3;
+            dev_floats = std::max(dev_floats, pitch * args->part_span);
+        }
+        if (int grown = rt::ensure_device_fb(be, dev_floats)) return grown;
 
-    // device mirrors of the requested id arrays
-    std::vector<void *> tmp;
-    RtRayIds dev{};
-    struct Copy {
-        int32_t *host, *dev;
-        size_t count;
-    };
-    std::vector<Copy> copies;
-    auto cleanup = [&]() { free_all(tmp); };
-    if (ids_host) {
-        const size_t npl = ds->n_point_lights;
-        struct Want {
-            int32_t *host;
-            int32_t **dev;
+        // device mirrors of the requested id arrays
+        std::vector<void *> tmp;
+        RtRayIds dev{};
+        struct Copy {
+            int32_t *host, *dev;
             size_t count;
-        } wants[] = {{ids_host->primary_shape, &dev.primary_shape, samples}, {ids_host->primary_tri, &dev.primary_tri, samples},
-                     {ids_host->final_shape, &dev.final_shape, samples},     {ids_host->final_tri, &dev.final_tri, samples},
-                     {ids_host->bounces, &dev.bounces, samples},             {ids_host->shadow_shape, &dev.shadow_shape, samples * npl},
-                     {ids_host->shadow_tri, &dev.shadow_tri, samples * npl}};
-        for (auto &w : wants) {
-            if (!w.host || w.count == 0) continue;
-            void *p = nullptr;
-            hipError_t e = hipMalloc(&p, w.count * sizeof(int32_t));
-            if (e != hipSuccess) {
-                cleanup();
-                return rt::set_error(RT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+        };
+        std::vector<Copy> copies;
+        auto cleanup = [&]() { free_all(tmp); };
+        if (ids_host) {
+            const size_t npl = ds->n_point_lights;
+            struct Want {
+                int32_t *host;
+                int32_t **dev;
+                size_t count;
+            } wants[] = {{ids_host->primary_shape, &dev.primary_shape, samples}, {ids_host->primary_tri, &dev.primary_tri, samples},
+                         {ids_host->final_shape, &dev.final_shape, samples},     {ids_host->final_tri, &dev.final_tri, samples},
+                         {ids_host->bounces, &dev.bounces, samples},             {ids_host->shadow_shape, &dev.shadow_shape, samples * npl},
+                         {ids_host->shadow_tri, &dev.shadow_tri, samples * npl}};
+            for (auto &w : wants) {
+                if (!w.host || w.count == 0) continue;
+                void *p = nullptr;
+                hipError_t e = hipMalloc(&p, w.count * sizeof(int32_t));
+                if (e != hipSuccess) {
+                    cleanup();
+                    return rt::set_error(RT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+                }
+                tmp.push_back(p);
+                *w.dev = (int32_t *)p;
+                (void)hipMemsetAsync(p, 0xFF, w.count * sizeof(int32_t), be->stream);  // -1
+                copies.push_back({w.host, (int32_t *)p, w.count});
             }
-            tmp.push_back(p);
-            *w.dev = (int32_t *)p;
-            (void)hipMemsetAsync(p, 0xFF, w.count * sizeof(int32_t), be->stream);  // -1
-            copies.push_back({w.host, (int32_t *)p, w.count});
         }
-    }
-    // The kernels are only enqueued here (statistics and a progress callback excepted, which make
-    // render_frame wait); the copy of the frame follows on the same stream, and ONE wait ends the call.
-    int rc = rt::render_frame(be, ds, args, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out, true, false);
-    if (rc) {
-        cleanup();
-        return rc;
-    }
-    auto fail = [&](hipError_t e, const char *what) {
-        cleanup();
-        return rt::set_error(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
-    };
-    // what to bring over: the frame, or the owned tiles of a part (tile-major, scattered below)
-    // (with part_span the parts' blocks lie a pitch apart: up to the last place that holds a tile)
-    size_t places = be->tile_list_host.size();
-    for (int32_t at : be->tile_place_host) places = std::max(places, (size_t)at + 1);
-    const size_t copy_floats = parts > 1 ? places * tw * th * 3 : fb_floats;
-    const bool direct = parts <= 1 && rt::is_pinned_host(fb_rgb);  // the device can write the caller's memory itself
-    float *landing = fb_rgb;
-    if (!direct) {
-        if (int grown = rt::ensure_pinned(be, std::max<size_t>(copy_floats, 1))) {
+        // The kernels are only enqueued here (statistics and a progress callback excepted, which make
+        // render_frame wait); the copy of the frame follows on the same stream, and ONE wait ends the call.
+        int rc = rt::render_frame(be, ds, args, be->fb, ids_host ? &dev : nullptr, be->stream, stats_out, true, false);
+        if (rc) {
             cleanup();
-            return grown;
+            return rc;
         }
-        landing = be->pinned;
-    }
-    if (copy_floats) {
-        hipError_t e = hipMemcpyAsync(landing, be->fb, copy_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream);
-        if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
-    }
-    for (auto &c : copies) {  // pageable destinations: the runtime stages these itself
-        hipError_t e = hipMemcpyAsync(c.host, c.dev, c.count * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream);
-        if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
-    }
-    if ((rc = rt::finish_stream(be, be->stream))) {
+        auto fail = [&](hipError_t e, const char *what) {
+            cleanup();
+            return rt::set_error(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+        };
+        // what to bring over: the frame, or the owned tiles of a part (tile-major, scattered below)
+        // (with part_span the parts' blocks lie a pitch apart: up to the last place that holds a tile)
+        size_t places = be->tile_list_host.size();
+        for (int32_t at : be->tile_place_host) places = std::max(places, (size_t)at + 1);
+        const size_t copy_floats = parts > 1 ? places * tw * th * 3 : fb_floats;
+        const bool direct = parts <= 1 && rt::is_pinned_host(fb_rgb);  // the device can write the caller's memory itself
+        float *landing = fb_rgb;
+        if (!direct) {
+            if (int grown = rt::ensure_pinned(be, std::max<size_t>(copy_floats, 1))) {
+                cleanup();
+                return grown;
+            }
+            landing = be->pinned;
+        }
+        if (copy_floats) {
+            hipError_t e = hipMemcpyAsync(landing, be->fb, copy_floats * sizeof(float), hipMemcpyDeviceToHost, be->stream);
+            if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
+        }
+        for (auto &c : copies) {  // pageable destinations: the runtime stages these itself
+            hipError_t e = hipMemcpyAsync(c.host, c.dev, c.count * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream);
+            if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
+        }
+        if ((rc = rt::finish_stream(be, be->stream))) {
+            cleanup();
+            return rc;
+        }
+        if (parts > 1) {
+            // compact tile-major -> full layout, owned pixels only
+            for (size_t s = 0; s < be->tile_list_host.size(); ++s) {
+                const uint32_t tile = (uint32_t)be->tile_list_host[s];
+                const uint32_t x0 = (tile % tiles_x) * tw, y0 = (tile / tiles_x) * th;
+                const uint32_t w_in = std::min<uint32_t>(tw, (uint32_t)W - x0), h_in = std::min<uint32_t>(th, (uint32_t)H - y0);
+                const size_t at = be->tile_place_host.empty() ? s : (size_t)be->tile_place_host[s];
+                for (uint32_t y = 0; y < h_in; ++y)
+                    std::memcpy(fb_rgb + ((size_t)x0 + (size_t)(y0 + y) * W) * 3, landing + (at * tw * th + (size_t)y * tw) * 3,
+                                (size_t)w_in * 3 * sizeof(float));
+            }
+        } else if (!direct) {
+            std::memcpy(fb_rgb, landing, fb_floats * sizeof(float));
+        }
         cleanup();
-        return rc;
-    }
-    if (parts > 1) {
-        // compact tile-major -> full layout, owned pixels only
-        for (size_t s = 0; s < be->tile_list_host.size(); ++s) {
-            const uint32_t tile = (uint32_t)be->tile_list_host[s];
-            const uint32_t x0 = (tile % tiles_x) * tw, y0 = (tile / tiles_x) * th;
-            const uint32_t w_in = std::min<uint32_t>(tw, (uint32_t)W - x0), h_in = std::min<uint32_t>(th, (uint32_t)H - y0);
-            const size_t at = be->tile_place_host.empty() ? s : (size_t)be->tile_place_host[s];
-            for (uint32_t y = 0; y < h_in; ++y)
-                std::memcpy(fb_rgb + ((size_t)x0 + (size_t)(y0 + y) * W) * 3, landing + (at * tw * th + (size_t)y * tw) * 3,
-                            (size_t)w_in * 3 * sizeof(float));
-        }
-    } else if (!direct) {
-        std::memcpy(fb_rgb, landing, fb_floats * sizeof(float));
-    }
-    cleanup();
-    return RT_OK;
+        return RT_OK;
+    });
 }
 
 extern "C" int rt_partition_info(uint32_t width, uint32_t height, const RtRenderArgs *args, uint32_t *tiles_total,
                                  uint32_t *tiles_owned, uint32_t *tiles_owned_max) {
-    if (!args) return rt::set_error(RT_ERR_INVALID, "null argument");
-    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    if (int bad = check_partition(args)) return bad;
-    const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
-    const std::vector<uint32_t> per_part = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight);
-    if (tiles_total) *tiles_total = tiles_x * tiles_y;
-    if (tiles_owned) *tiles_owned = per_part[args->part_index];
-    if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());
-    return RT_OK;
+    return rt::guarded([&]() -> int {
+        if (!args) return rt::set_error(RT_ERR_INVALID, "null argument");
+        const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+        const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+        if (int bad = check_partition(args)) return bad;
+        uint32_t tiles_x, tiles_y;
+        if (int bad = tile_grid(width, height, tw, th, tiles_x, tiles_y)) return bad;
+        const std::vector<uint32_t> per_part = part_tile_counts(tiles_x, tiles_y, parts, args->part0_weight);
+        if (tiles_total) *tiles_total = tiles_x * tiles_y;
+        if (tiles_owned) *tiles_owned = per_part[args->part_index];
+        if (tiles_owned_max) *tiles_owned_max = *std::max_element(per_part.begin(), per_part.end());
+        return RT_OK;
+    });
 }
 
 extern "C" int rt_partition_tiles(uint32_t width, uint32_t height, const RtRenderArgs *args, int32_t *tiles_out,
                                   uint32_t capacity, uint32_t *count_out) {
-    if (!args || !count_out) return rt::set_error(RT_ERR_INVALID, "null argument");
-    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    if (int bad = check_partition(args)) return bad;
-    std::vector<int32_t> tiles;
-    owned_tiles((width + tw - 1) / tw, (height + th - 1) / th, args->part_index, parts, args->part0_weight, tiles);
-    *count_out = (uint32_t)tiles.size();
-    if (tiles_out) {
-        if (capacity < tiles.size()) return rt::set_error(RT_ERR_INVALID, "tile buffer too small");
-        std::memcpy(tiles_out, tiles.data(), tiles.size() * sizeof(int32_t));
-    }
-    return RT_OK;
+    return rt::guarded([&]() -> int {
+        if (!args || !count_out) return rt::set_error(RT_ERR_INVALID, "null argument");
+        const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+        const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+        if (int bad = check_partition(args)) return bad;
+        std::vector<int32_t> tiles;
+        uint32_t tiles_x, tiles_y;
+        if (int bad = tile_grid(width, height, tw, th, tiles_x, tiles_y)) return bad;
+        owned_tiles(tiles_x, tiles_y, args->part_index, parts, args->part0_weight, tiles);
+        *count_out = (uint32_t)tiles.size();
+        if (tiles_out) {
+            if (capacity < tiles.size()) return rt::set_error(RT_ERR_INVALID, "tile buffer too small");
+            std::memcpy(tiles_out, tiles.data(), tiles.size() * sizeof(int32_t));
+        }
+        return RT_OK;
+    });
 }
 
 extern "C" int rt_untile_device(RtBackend *be, uint32_t width, uint32_t height, const RtRenderArgs *args,
                                 const float *gathered_dev, float *fb_rgb_dev, void *hip_stream) {
-    return rt_untile_device_pitched(be, width, height, args, gathered_dev, 0, fb_rgb_dev, hip_stream);
+    return rt::guarded([&]() -> int {
+        return rt_untile_device_pitched(be, width, height, args, gathered_dev, 0, fb_rgb_dev, hip_stream);
+    });
 }
 
 extern "C" int rt_untile_device_pitched(RtBackend *be, uint32_t width, uint32_t height, const RtRenderArgs *args,
                                         const float *gathered_dev, size_t part_pitch_floats, float *fb_rgb_dev,
                                         void *hip_stream) {
-    if (!be || !args || !gathered_dev || !fb_rgb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
-    const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
-    const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
-    const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
-    uint32_t stride = 0;
-    int rc = rt_partition_info(width, height, args, nullptr, nullptr, &stride);
-    if (rc) return rc;
-    const size_t block_floats = (size_t)stride * tw * th * 3;
-    if (part_pitch_floats == 0) part_pitch_floats = block_floats;  // end to end
-    if (part_pitch_floats < block_floats) return rt::set_error(RT_ERR_INVALID, "part pitch smaller than a part's block of tiles");
-    if (parts > 4096 || stride >= (1u << 20)) return rt::set_error(RT_ERR_INVALID, "too many parts or tiles per part for the un-tile table");
-    if (args->part_rotation >= parts) return rt::set_error(RT_ERR_INVALID, "part_rotation must be below part_count");
-    RT_HIP(hipSetDevice(be->device));
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : be->stream;
-    const uint32_t key[5] = {width, height, tw, th, parts | (args->part0_weight << 24)};
-    if (std::memcmp(key, be->untile_key, sizeof(key)) != 0 || !be->tile_where) {
-        std::vector<uint32_t> where((size_t)tiles_x * tiles_y), next(parts, 0);
-        const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, args->part0_weight);
-        for (uint32_t ty = 0; ty < tiles_y; ++ty)
-            for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-                const uint32_t k = ty * tiles_x + tx, p = rt_tile_map_owner(map, tx, ty);
-                where[k] = (p << 20) | next[p]++;
-            }
-        if (be->tile_where) (void)hipFree(be->tile_where);
-        be->tile_where = nullptr;
-        RT_HIP(hipMalloc((void **)&be->tile_where, where.size() * sizeof(uint32_t)));
-        RT_HIP(hipMemcpy(be->tile_where, where.data(), where.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        std::memcpy(be->untile_key, key, sizeof(key));
-    }
-    const uint64_t untile_blocks = ((uint64_t)width * height + RT_UNTILE_BLOCK - 1) / RT_UNTILE_BLOCK;
-    hipLaunchKernelGGL(k_untile, dim3((uint32_t)std::min<uint64_t>(untile_blocks, 4u * RT_MAX_GRID)), dim3(RT_UNTILE_BLOCK), 0, stream,
-                       gathered_dev, part_pitch_floats, fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x, parts,
-                       (parts - args->part_rotation) % parts);
-    RT_HIP(hipGetLastError());
-    return RT_OK;
+    return rt::guarded([&]() -> int {
+        if (!be || !args || !gathered_dev || !fb_rgb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
+        const uint32_t tw = args->tile_w ? args->tile_w : 32, th = args->tile_h ? args->tile_h : 32;
+        const uint32_t parts = std::max<uint32_t>(args->part_count, 1);
+        uint32_t tiles_x, tiles_y;
+        if (int bad = tile_grid(width, height, tw, th, tiles_x, tiles_y)) return bad;
+        uint32_t stride = 0;
+        int rc = rt_partition_info(width, height, args, nullptr, nullptr, &stride);
+        if (rc) return rc;
+        const size_t block_floats = (size_t)stride * tw * th * 3;
+        if (part_pitch_floats == 0) part_pitch_floats = block_floats;  // end to end
+        if (part_pitch_floats < block_floats) return rt::set_error(RT_ERR_INVALID, "part pitch smaller than a part's block of tiles");
+        if (parts > 4096 || stride >= (1u << 20)) return rt::set_error(RT_ERR_INVALID, "too many parts or tiles per part for the un-tile table");
+        if (args->part_rotation >= parts) return rt::set_error(RT_ERR_INVALID, "part_rotation must be below part_count");
+        RT_HIP(hipSetDevice(be->device));
+        hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : be->stream;
+        const uint32_t key[5] = {width, height, tw, th, parts | (args->part0_weight << 24)};
+        if (std::memcmp(key, be->untile_key, sizeof(key)) != 0 || !be->tile_where) {
+            std::vector<uint32_t> where((size_t)tiles_x * tiles_y), next(parts, 0);
+            const RtTileMap map = rt_tile_map(tiles_x, tiles_y, parts, args->part0_weight);
+            for (uint32_t ty = 0; ty < tiles_y; ++ty)
+                for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+                    const uint32_t k = ty * tiles_x + tx, p = rt_tile_map_owner(map, tx, ty);
+                    where[k] = (p << 20) | next[p]++;
+                }
+            if (be->tile_where) (void)hipFree(be->tile_where);
+            be->tile_where = nullptr;
+            RT_HIP(hipMalloc((void **)&be->tile_where, where.size() * sizeof(uint32_t)));
+            RT_HIP(hipMemcpy(be->tile_where, where.data(), where.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            std::memcpy(be->untile_key, key, sizeof(key));
+        }
+        const uint64_t untile_blocks = ((uint64_t)width * height + RT_UNTILE_BLOCK - 1) / RT_UNTILE_BLOCK;
+        hipLaunchKernelGGL(k_untile, dim3((uint32_t)std::min<uint64_t>(untile_blocks, 4u * RT_MAX_GRID)), dim3(RT_UNTILE_BLOCK), 0, stream,
+                           gathered_dev, part_pitch_floats, fb_rgb_dev, be->tile_where, width, height, tw, th, tiles_x, parts,
+                           (parts - args->part_rotation) % parts);
+        RT_HIP(hipGetLastError());
+        return RT_OK;
+    });
 }
 
 extern "C" int rt_trace_rays(RtBackend *be, const RtDeviceScene *ds, uint64_t n, const double *origins,
                              const double *directions, const double *tmin, const double *tmax, int32_t mode,
                              float *t_out, int32_t *shape_out, int32_t *tri_out) {
-    if (!be || !ds || !origins || !directions || !tmin || !tmax || !t_out || !shape_out || !tri_out)
-        return rt::set_error(RT_ERR_INVALID, "null argument");
-    if (n == 0) return RT_OK;
-    RT_HIP(hipSetDevice(be->device));
-    std::vector<void *> tmp;
-    double *d_o = nullptr, *d_d = nullptr, *d_tmin = nullptr, *d_tmax = nullptr;
-    float *d_t = nullptr;
-    int32_t *d_shape = nullptr, *d_tri = nullptr;
-    uint32_t *d_over = nullptr;
-    int rc;
-    auto bail = [&](int code) {
+    return rt::guarded([&]() -> int {
+        if (!be || !ds || !origins || !directions || !tmin || !tmax || !t_out || !shape_out || !tri_out)
+            return rt::set_error(RT_ERR_INVALID, "null argument");
+        if (n == 0) return RT_OK;
+        RT_HIP(hipSetDevice(be->device));
+        std::vector<void *> tmp;
+        double *d_o = nullptr, *d_d = nullptr, *d_tmin = nullptr, *d_tmax = nullptr;
+        float *d_t = nullptr;
+        int32_t *d_shape = nullptr, *d_tri = nullptr;
+        uint32_t *d_over = nullptr;
+        int rc;
+        auto bail = [&](int code) {
+            free_all(tmp);
+            return code;
+        };
+        if ((rc = alloc_into(tmp, &d_o, n * 3)) || (rc = alloc_into(tmp, &d_d, n * 3)) || (rc = alloc_into(tmp, &d_tmin, n)) ||
+            (rc = alloc_into(tmp, &d_tmax, n)) || (rc = alloc_into(tmp, &d_t, n)) || (rc = alloc_into(tmp, &d_shape, n)) ||
+            (rc = alloc_into(tmp, &d_tri, n)) || (rc = alloc_into(tmp, &d_over, 1)))
+            return bail(rc);
+        if (hipMemcpy(d_o, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_d, directions, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_tmin, tmin, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_tmax, tmax, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(d_over, 0, sizeof(uint32_t)) != hipSuccess)
+            return bail(rt::set_error(RT_ERR_DEVICE, "hipMemcpy to device failed"));
+        const int mode_stack_depth = mode == RT_MODE_REFERENCE_ORDER ? ds->view.stack_depth : ds->view_fast.stack_depth;
+        const size_t lds_bytes = (size_t)(std::max(mode_stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
+        if (lds_bytes > 64 * 1024) return bail(rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack"));
+        if (mode == RT_MODE_REFERENCE_ORDER)
+            hipLaunchKernelGGL((k_trace_user<false, true>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
+        else
+            hipLaunchKernelGGL((k_trace_user<true, false>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view_fast, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
+        uint32_t over = 0;
+        if (hipStreamSynchronize(be->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
+            hipMemcpy(t_out, d_t, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(shape_out, d_shape, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(tri_out, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&over, d_over, sizeof(over), hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(rt::set_error(RT_ERR_DEVICE, "trace kernel or copy back failed"));
         free_all(tmp);
-        return code;
-    };
-    if ((rc = alloc_into(tmp, &d_o, n * 3)) || (rc = alloc_into(tmp, &d_d, n * 3)) || (rc = alloc_into(tmp, &d_tmin, n)) ||
-        (rc = alloc_into(tmp, &d_tmax, n)) || (rc = alloc_into(tmp, &d_t, n)) || (rc = alloc_into(tmp, &d_shape, n)) ||
-        (rc = alloc_into(tmp, &d_tri, n)) || (rc = alloc_into(tmp, &d_over, 1)))
-        return bail(rc);
-    if (hipMemcpy(d_o, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_d, directions, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_tmin, tmin, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_tmax, tmax, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(d_over, 0, sizeof(uint32_t)) != hipSuccess)
-        return bail(rt::set_error(RT_ERR_DEVICE, "hipMemcpy to device failed"));
-    const int mode_stack_depth = mode == RT_MODE_REFERENCE_ORDER ? ds->view.stack_depth : ds->view_fast.stack_depth;
-    const size_t lds_bytes = (size_t)(std::max(mode_stack_depth, 1) + RT_LDS_AUX_ROWS) * RT_BLOCK * sizeof(int32_t);
-    if (lds_bytes > 64 * 1024) return bail(rt::set_error(RT_ERR_UNSUPPORTED, "scene trees too deep for the LDS traversal stack"));
-    if (mode == RT_MODE_REFERENCE_ORDER)
-        hipLaunchKernelGGL((k_trace_user<false, true>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
-    else
-        hipLaunchKernelGGL((k_trace_user<true, false>), dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, be->stream, ds->view_fast, n, d_o, d_d, d_tmin, d_tmax, d_t, d_shape, d_tri, d_over);
-    uint32_t over = 0;
-    if (hipStreamSynchronize(be->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
-        hipMemcpy(t_out, d_t, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(shape_out, d_shape, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(tri_out, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&over, d_over, sizeof(over), hipMemcpyDeviceToHost) != hipSuccess)
-        return bail(rt::set_error(RT_ERR_DEVICE, "trace kernel or copy back failed"));
-    free_all(tmp);
-    if (over) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
-    return RT_OK;
+        if (over) return rt::set_error(RT_ERR_DEVICE, "traversal stack overflow (internal error)");
+        return RT_OK;
+    });
 }

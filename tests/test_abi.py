@@ -68,6 +68,13 @@ def test_host_only_entry_points_need_no_gpu(rt):
     a.part_index = 9
     assert rt.lib().rt_partition_info(1000, 1000, C.byref(a), C.byref(total), C.byref(owned), C.byref(owned_max)) == rt.RT_ERR_INVALID
     assert b"part" in rt.lib().rt_last_error()
+    # nor is an absurd frame: refused before anything is sized for it (tile counts are computed in 64 bits)
+    a.part_index = 1
+    for w, h in ((0xFFFFFFFF, 0xFFFFFFFF), (1 << 20, 1 << 20)):
+        assert rt.lib().rt_partition_info(w, h, C.byref(a), C.byref(total), C.byref(owned), C.byref(owned_max)) == rt.RT_ERR_INVALID
+        assert b"too large" in rt.lib().rt_last_error()
+    count = C.c_uint32()
+    assert rt.lib().rt_partition_tiles(0xFFFFFFFF, 0xFFFFFFFF, C.byref(a), None, 0, C.byref(count)) == rt.RT_ERR_INVALID
 
 
 def test_partition_is_balanced_and_interleaved(rt):
