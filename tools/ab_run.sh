@@ -13,7 +13,7 @@ rm -f gpurun_out/ab/a.npz gpurun_out/ab/b.npz
 for round in 1 2; do for v in A B; do
   lib=$A; [ $v = B ] && lib=$B
   for wl in cornell_room bunny spheres_1K; do
-    RT_HIP_LIB=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 5 --workload $wl 2> gpurun_out/ab/$v_$wl.err | tail -n 1 > gpurun_out/ab/${v}_$wl.json || { tail -3 gpurun_out/ab/$v_$wl.err; exit 1; }
+    RT_HIP_LIB=$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 5 --workload $wl 2> gpurun_out/ab/${v}_$wl.err | tail -n 1 > gpurun_out/ab/${v}_$wl.json || { tail -3 gpurun_out/ab/${v}_$wl.err; exit 1; }
     python3 -c "import json; d=json.load(open('gpurun_out/ab/${v}_$wl.json')); print('$v $wl', round(d['ms_per_step'],4), {k: round(x,4) for k,x in d['kernel_ms_per_step'].items() if x})"
   done
 done; done
