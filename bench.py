@@ -146,8 +146,12 @@ class Frames:
         self.flights = flights
         self.backends = [rt.Backend(ctx.local_rank) for _ in range(flights)]
         t_up = time.perf_counter()
-        self.devs = [be.upload(scene) for be in self.backends]
-        self.upload_s = (time.perf_counter() - t_up) / flights
+        if os.environ.get("RT_BENCH_SHARE_SCENE", "1") == "1":  # one copy of the scene for all frames in flight
+            first = self.backends[0].upload(scene)
+            self.devs = [first] + [first.on(be) for be in self.backends[1:]]
+        else:
+            self.devs = [be.upload(scene) for be in self.backends]
+        self.upload_s = (time.perf_counter() - t_up) / len({int(d.handle.value) for d in self.devs})
         self.dev = self.devs[0]
         # Streams of our own: the backend treats a null stream handle as "use the backend's private stream", which
         # would not be ordered with torch's copies.
@@ -850,6 +854,7 @@ def main():
                        "timed_region": "all ranks start behind a barrier with idle GPUs; each stops its clock when its last frame is in host "
                                        "memory; the maximum over the ranks is taken",
                        "render_flags": args.render_flags,
+                       "scene_copies_per_gpu": len({int(d.handle.value) for d in run.devs}),  # the frames in flight share one uploaded scene
                        "scene_upload_ms": run.upload_s * 1e3,
                        "kernel_split_from": "last warm-up frame (fully instrumented, every kernel alone on the GPU)"},
             "kernel_ms_per_step": {rt.KERNEL_CLASSES[k]: k_ms[k] / span for k in range(len(rt.KERNEL_CLASSES))},

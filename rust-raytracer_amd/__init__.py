@@ -645,8 +645,18 @@ class DeviceScene:
 
     def close(self) -> None:
         if self._h:
-            lib().rt_scene_free(self._h)
+            if getattr(self, "_lender", None) is None:
+                lib().rt_scene_free(self._h)
             self._h = C.c_void_p()
+
+    def on(self, backend: Backend) -> "DeviceScene":
+        """The same uploaded scene, rendered through another backend of the same GPU: a scene on the device is only
+        read, so frames in flight on several backends can share one copy of the trees (and the caches hold one).
+        The view does not own the scene: close the original after the last frame through any view."""
+        view = DeviceScene.__new__(DeviceScene)
+        view.__dict__.update(self.__dict__)
+        view.backend, view._lender = backend, self
+        return view
 
     def __del__(self):
         try:

@@ -1779,7 +1779,7 @@ struct FramePlan {
 int plan_frame(const RtBackend *be, const RtDeviceScene *ds, const RtRenderArgs *args, const float *fb_dev, bool with_stats,
                bool blocking, bool static_memory, FramePlan &P) {
     if (!be || !ds || !args || !fb_dev) return rt::set_error(RT_ERR_INVALID, "null argument");
-    if (ds->backend != be) return rt::set_error(RT_ERR_INVALID, "scene was uploaded through another backend");
+    if (ds->device != be->device) return rt::set_error(RT_ERR_INVALID, "scene was uploaded to another GPU than the backend's");
     if (args->antialias_method < RT_AA_NORMAL || args->antialias_method > RT_AA_RANDOM)
         return rt::set_error(RT_ERR_INVALID, "antialias_method must be RT_AA_NORMAL, RT_AA_JITTERED or RT_AA_RANDOM");
     P.n = args->sqrt_rays_per_pixel;

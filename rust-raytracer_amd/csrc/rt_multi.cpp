@@ -298,7 +298,7 @@ extern "C" int rt_multi_create(RtBackend *const *bes, RtDeviceScene *const *dss,
         *out = nullptr;
         for (uint32_t k = 0; k < n; ++k) {
             if (!bes[k] || !dss[k]) return rt::set_error(RT_ERR_INVALID, "null backend or scene");
-            if (dss[k]->backend != bes[k]) return rt::set_error(RT_ERR_INVALID, "scene k must be uploaded through backend k");
+            if (dss[k]->device != bes[k]->device) return rt::set_error(RT_ERR_INVALID, "scene k must lie on backend k's GPU");
             if (dss[k]->width != dss[0]->width || dss[k]->height != dss[0]->height)
                 return rt::set_error(RT_ERR_INVALID, "the scenes of the parts differ in size");
             for (uint32_t j = 0; j < k; ++j)

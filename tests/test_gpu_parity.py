@@ -540,6 +540,53 @@ def test_frames_in_flight_on_several_backends(rt, backend, scene_path):
         b.close()
 
 
+def test_one_uploaded_scene_shared_by_several_backends(rt, backend, scene_path):
+    """A scene on the device is only read: four backends render ONE uploaded copy at the same time, each on its own
+    stream, different frames of it (sample counts, modes, seeds, a window, the static work memory), also with the
+    statistics of a blocking render; every frame equals the one rendered through the backend that uploaded."""
+    import torch
+
+    W, H = 256, 160
+    scene = rt.parse_scene_file(scene_path("mixed_features"), image_width=W, image_height=H, recursion_depth=5)
+    dev = backend.upload(scene)
+    others = [rt.Backend(0) for _ in range(3)]
+    views = [dev] + [dev.on(b) for b in others]
+    jobs = [dict(n=3), dict(n=2, antialias_method=1, seed=9), dict(n=2, mode=rt.RT_MODE_REFERENCE_ORDER), dict(n=3, window=(40, 30, 128, 64))]
+    alone = []
+    for kw in jobs:
+        kw = dict(kw)
+        fb, _, _ = dev.render(kw.pop("n"), **kw)
+        alone.append(fb.pixels.copy())
+    streams = [torch.cuda.Stream() for _ in jobs]
+    rounds = 5
+    out = [[torch.zeros(a.size, dtype=torch.float32, device="cuda") for _ in range(rounds)] for a in alone]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for k, kw in enumerate(jobs):
+            kw = dict(kw)
+            a = views[k].render_args(kw.pop("n"), **kw)
+            views[k].render_device(a, out[k][r].data_ptr(), stream=streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(len(jobs)):
+        for r in range(rounds):
+            assert np.array_equal(out[k][r].cpu().numpy().reshape(alone[k].shape), alone[k]), (jobs[k], r)
+    fb, ids, stats = views[2].render(3, want_ids=True)  # a blocking render with ids and statistics through a borrowed scene
+    fb0, ids0, stats0 = dev.render(3, want_ids=True)
+    assert np.array_equal(fb.pixels, fb0.pixels) and np.array_equal(ids.shadow_shape, ids0.shadow_shape) and stats.total_rays() == stats0.total_rays()
+    whole = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    views[3].render_device_static(views[3].render_args(3), whole.data_ptr())
+    others[2].sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(whole.cpu().numpy().reshape(H, W, 3), alone[0])
+    for v in views[1:]:
+        v.close()  # (views own nothing)
+    again, _, _ = dev.render(3)
+    assert np.array_equal(again.pixels, alone[0])
+    dev.close()
+    for b in others:
+        b.close()
+
+
 def test_trace_rays_matches_oracle(rt, backend, scene_path):
     """rt_trace_rays (BVH::closest_hit, geometry/bvh.rs:140) on rays that are not camera rays."""
     scene = rt.parse_scene_file(scene_path("mixed_features"))

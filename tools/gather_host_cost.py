@@ -38,7 +38,8 @@ def main():
     scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
                                 recursion_depth=depth)
     bes = [rt.Backend(0) for _ in range(flights)]
-    devs = [b.upload(scene) for b in bes]
+    first = bes[0].upload(scene)  # one copy of the scene for all frames in flight
+    devs = [first] + [first.on(b) for b in bes[1:]]
     a = devs[0].render_args(n, tile=(tile, tile), part=(0, parts), part0_weight=int(os.environ.get("RT_PART0_WEIGHT", "0")))
     _, owned, stride = devs[0].partition_info(a)
     pf = stride * tile * tile * 3

@@ -28,7 +28,8 @@ def main():
     scene = rt.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".json"), image_width=W, image_height=H,
                                 recursion_depth=depth)
     bes = [rt.Backend(0) for _ in range(flights)]
-    devs = [b.upload(scene) for b in bes]
+    first = bes[0].upload(scene)  # one copy of the scene for all frames in flight
+    devs = [first] + [first.on(b) for b in bes[1:]]
     sts = [torch.cuda.Stream() for _ in range(flights)]
     bufs = [torch.zeros(W * H * 3 + 40 * 40 * 3 * 700, dtype=torch.float32, device="cuda") for _ in range(flights)]
 

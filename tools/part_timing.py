@@ -31,7 +31,8 @@ def main():
                                 recursion_depth=depth)
     flights = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # frames in flight: one backend + stream each
     bes = [rt.Backend(0) for _ in range(flights)]
-    devs = [b.upload(scene) for b in bes]
+    first = bes[0].upload(scene)  # one copy of the scene for all frames in flight
+    devs = [first] + [first.on(b) for b in bes[1:]]
     sts = [torch.cuda.Stream() for _ in range(flights)]
     whole = None
     for parts in (1, 2, 4, 8):

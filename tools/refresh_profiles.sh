@@ -10,8 +10,8 @@ for WL in "$@"; do
   cp $SRC/bench.json $DST/bench.json
   cp $SRC/summary.json $DST/pmc_summary.json
   cp $SRC/summary.txt $DST/pmc_summary.txt
-  cp $(find $SRC/trace -name "*kernel_stats.csv" | head -n 1) $DST/kernel_stats.csv
-  cp $(find $SRC/trace_solo -name "*kernel_stats.csv" | head -n 1) $DST/kernel_stats_solo.csv
+  cp $(ls -t $(find $SRC/trace -name "*kernel_stats.csv") | head -n 1) $DST/kernel_stats.csv   # (the newest: gpurun merges every run's files into the same directory)
+  cp $(ls -t $(find $SRC/trace_solo -name "*kernel_stats.csv") | head -n 1) $DST/kernel_stats_solo.csv
   echo "$DST: $(ls $DST | tr '\n' ' ')"
 done
 # the counter figures bench.py reads (each gpu_profile.sh run merges its workload into the box's copy; the copy
